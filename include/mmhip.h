@@ -1,0 +1,118 @@
+/*
+ * mmhip.h -- C ABI of the MI355X-native MathMap pixel engine (libmathmap_hip.so).
+ *
+ * Standalone tier: compile a .mm filter, bind user values / input images, render
+ * rows on the GPU.  Mirrors the life cycle of the reference's session API
+ * (mathmap.h:274-299, mathmap_common.c):
+ *
+ *   mmhip_compile        ~ compile_mathmap        (mathmap_common.c:503-582)
+ *   mmhip_invoke         ~ invoke_mathmap         (mathmap_common.c:746-795)
+ *   mmhip_set_*          ~ -D name=value handling (mathmap_cmdline.c:756-796)
+ *   mmhip_render         ~ invocation_new_frame + call_invocation_parallel_and_join
+ *                          (mathmap_common.c:797-1018); one launch renders the row band
+ *   mmhip_unload         ~ unload_mathmap / free_invocation
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * Every function returning int returns 0 on success and a negative value on
+ * error; mmhip_last_error() then holds the message (the reference's error_string,
+ * exprtree.c:40).  The reference-ABI tier (gen_and_load_hip_code) is declared in
+ * mathmap_hip_backend.h.
+ */
+#ifndef MMHIP_H
+#define MMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmhip_filter mmhip_filter;
+typedef struct mmhip_invocation mmhip_invocation;
+
+/* user value kinds (userval.h:34-42) */
+enum { MMHIP_UV_INT = 0, MMHIP_UV_FLOAT = 1, MMHIP_UV_BOOL = 2, MMHIP_UV_COLOR = 3,
+       MMHIP_UV_CURVE = 4, MMHIP_UV_GRADIENT = 5, MMHIP_UV_IMAGE = 6 };
+
+/* edge behaviours (mathmap.h:134-147) */
+enum { MMHIP_EDGE_COLOR = 0, MMHIP_EDGE_WRAP = 1, MMHIP_EDGE_REFLECT = 2, MMHIP_EDGE_ROTATE = 3 };
+
+typedef struct mmhip_options {
+    int intersample;      /* 1 = bilinear input sampling (CLI -i), 0 = nearest */
+    int supersampling;    /* affects the nearest fetch only (builtins.c:154-158) */
+    int edge_behaviour_x, edge_behaviour_y;
+    int tile_w;           /* workgroup tile width in pixels: 8,16,32,64,128,256 (0 = default) */
+    int reserved[8];
+} mmhip_options;
+
+typedef struct mmhip_userval_info {
+    int kind;
+    int index;
+    char name[64];
+    int int_min, int_max, int_default;
+    float float_min, float_max, float_default;
+    int bool_default;
+    unsigned image_flags;
+} mmhip_userval_info;
+
+const char *mmhip_last_error(void);
+const char *mmhip_version(void);
+
+/* ---- compile (no GPU needed up to mmhip_filter_load) ---- */
+void mmhip_default_options(mmhip_options *o);
+mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts);
+void mmhip_filter_free(mmhip_filter *f);
+const char *mmhip_filter_name(const mmhip_filter *f);
+int mmhip_filter_num_uservals(const mmhip_filter *f);
+int mmhip_filter_userval_info(const mmhip_filter *f, int index, mmhip_userval_info *out);
+const char *mmhip_filter_ir_json(mmhip_filter *f);        /* IR dump, see oracle/ccgen.py */
+const char *mmhip_filter_kernel_source(mmhip_filter *f);  /* the HIP C++ handed to hiprtc */
+int mmhip_filter_num_native_calls(const mmhip_filter *f);
+/* hiprtc-compiles for gfx950 and (if a device is present) loads the module.
+   load_module = 0 only compiles (usable without a GPU).  Returns code size. */
+long mmhip_filter_jit(mmhip_filter *f, int load_module);
+double mmhip_filter_jit_seconds(const mmhip_filter *f);
+
+/* ---- invocation ---- */
+mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height);
+void mmhip_invocation_free(mmhip_invocation *inv);
+int mmhip_set_int(mmhip_invocation *inv, int index, int value);
+int mmhip_set_float(mmhip_invocation *inv, int index, float value);
+int mmhip_set_bool(mmhip_invocation *inv, int index, int value);
+int mmhip_set_color(mmhip_invocation *inv, int index, float r, float g, float b, float a);
+int mmhip_set_by_name(mmhip_invocation *inv, const char *name, const char *value);  /* -Dname=value */
+/* Input image from host memory: channels = 3 (RGB8, alpha forced to 255 as
+   mathmap_cmdline.c:183 does) or 4 (RGBA8).  Uploaded once, stays in HBM. */
+int mmhip_set_image_host(mmhip_invocation *inv, int index, const uint8_t *pixels, int width, int height, int channels);
+/* Input image already resident in HBM as packed 0xRRGGBBAA uint32 per pixel. */
+int mmhip_set_image_device(mmhip_invocation *inv, int index, const void *device_rgba32, int width, int height);
+int mmhip_set_edge_colors(mmhip_invocation *inv, uint32_t color_x, uint32_t color_y);
+int mmhip_set_render_size(mmhip_invocation *inv, int render_width, int render_height);
+
+/* Renders rows [first_row, last_row) of region (region_x, region_y, region_w, region_h)
+   at animation parameter t / frame into device memory `out_device` (row 0 of the
+   band at out_device; bpp bytes per pixel, row_stride bytes per row; floatmap != 0
+   writes float[4] per pixel instead).  `stream` is a hipStream_t (NULL = the
+   invocation's own stream).  Asynchronous. */
+int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
+                 int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream);
+/* Convenience: whole frame to a host RGBA8 buffer (width*height*4 bytes); synchronous. */
+int mmhip_render_host(mmhip_invocation *inv, int frame, float t, uint8_t *out_rgba);
+int mmhip_sync(mmhip_invocation *inv);
+/* Average device time (ms) of the last pixel-kernel launch as measured with HIP
+   events on the launch stream; requires mmhip_enable_timing(inv, 1). */
+int mmhip_enable_timing(mmhip_invocation *inv, int on);
+double mmhip_last_kernel_ms(mmhip_invocation *inv);
+
+/* device memory helpers for callers without their own allocator */
+void *mmhip_device_alloc(size_t bytes);
+void mmhip_device_free(void *p);
+int mmhip_copy_to_host(void *dst_host, const void *src_device, size_t bytes);
+int mmhip_copy_to_device(void *dst_device, const void *src_host, size_t bytes);
+int mmhip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

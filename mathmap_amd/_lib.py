@@ -1,0 +1,83 @@
+"""ctypes binding of libmathmap_hip.so (the C ABI declared in include/mmhip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C mathmap_amd/csrc``.
+There is deliberately no Python or CPU fallback: if the shared object is missing the
+import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmathmap_hip.so")
+
+
+class Options(C.Structure):
+    _fields_ = [("intersample", C.c_int), ("supersampling", C.c_int),
+                ("edge_behaviour_x", C.c_int), ("edge_behaviour_y", C.c_int),
+                ("tile_w", C.c_int), ("reserved", C.c_int * 8)]
+
+
+class UservalInfo(C.Structure):
+    _fields_ = [("kind", C.c_int), ("index", C.c_int), ("name", C.c_char * 64),
+                ("int_min", C.c_int), ("int_max", C.c_int), ("int_default", C.c_int),
+                ("float_min", C.c_float), ("float_max", C.c_float), ("float_default", C.c_float),
+                ("bool_default", C.c_int), ("image_flags", C.c_uint)]
+
+
+# every symbol include/mmhip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mmhip_last_error": (C.c_char_p, []),
+    "mmhip_version": (C.c_char_p, []),
+    "mmhip_default_options": (None, [C.POINTER(Options)]),
+    "mmhip_compile": (C.c_void_p, [C.c_char_p, C.POINTER(Options)]),
+    "mmhip_filter_free": (None, [C.c_void_p]),
+    "mmhip_filter_name": (C.c_char_p, [C.c_void_p]),
+    "mmhip_filter_num_uservals": (C.c_int, [C.c_void_p]),
+    "mmhip_filter_userval_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(UservalInfo)]),
+    "mmhip_filter_ir_json": (C.c_char_p, [C.c_void_p]),
+    "mmhip_filter_kernel_source": (C.c_char_p, [C.c_void_p]),
+    "mmhip_filter_num_native_calls": (C.c_int, [C.c_void_p]),
+    "mmhip_filter_jit": (C.c_long, [C.c_void_p, C.c_int]),
+    "mmhip_filter_jit_seconds": (C.c_double, [C.c_void_p]),
+    "mmhip_invoke": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "mmhip_invocation_free": (None, [C.c_void_p]),
+    "mmhip_set_int": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mmhip_set_float": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "mmhip_set_bool": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mmhip_set_color": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "mmhip_set_by_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "mmhip_set_image_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mmhip_set_image_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "mmhip_set_edge_colors": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "mmhip_set_render_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mmhip_render": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mmhip_render_host": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "mmhip_sync": (C.c_int, [C.c_void_p]),
+    "mmhip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "mmhip_last_kernel_ms": (C.c_double, [C.c_void_p]),
+    "mmhip_device_alloc": (C.c_void_p, [C.c_size_t]),
+    "mmhip_device_free": (None, [C.c_void_p]),
+    "mmhip_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mmhip_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mmhip_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library (once) and declares the prototypes."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mathmap_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

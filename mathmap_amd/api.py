@@ -1,0 +1,183 @@
+"""Python mirror of the reference's session interface for the per-pixel path.
+
+Names follow the reference: a *filter* is compiled (``compile_mathmap``,
+mathmap_common.c:503), *invoked* on a canvas size (``invoke_mathmap``, :746), user
+values are set like the CLI's ``-Dname=value`` (mathmap_cmdline.c:756-796) and frames
+are rendered (``call_invocation_parallel_and_join``, :1008).  All compute happens in
+libmathmap_hip.so on the GPU.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+
+from ._lib import Options, UservalInfo, lib
+
+UV_INT, UV_FLOAT, UV_BOOL, UV_COLOR, UV_CURVE, UV_GRADIENT, UV_IMAGE = range(7)
+EDGE_COLOR, EDGE_WRAP, EDGE_REFLECT, EDGE_ROTATE = range(4)
+
+
+class MathMapError(RuntimeError):
+    pass
+
+
+def _err():
+    return lib().mmhip_last_error().decode("utf-8", "replace")
+
+
+class Filter:
+    """A compiled .mm filter (front-end + IR + generated HIP kernel string)."""
+
+    def __init__(self, source, intersample=True, supersampling=False, edge_x=EDGE_COLOR, edge_y=EDGE_COLOR,
+                 tile_w=0):
+        o = Options()
+        lib().mmhip_default_options(C.byref(o))
+        o.intersample = 1 if intersample else 0
+        o.supersampling = 1 if supersampling else 0
+        o.edge_behaviour_x, o.edge_behaviour_y = edge_x, edge_y
+        o.tile_w = tile_w
+        self._h = lib().mmhip_compile(source.encode(), C.byref(o))
+        if not self._h:
+            raise MathMapError(_err())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().mmhip_filter_free(h)
+
+    @property
+    def name(self):
+        return lib().mmhip_filter_name(self._h).decode()
+
+    @property
+    def uservals(self):
+        out = []
+        for i in range(lib().mmhip_filter_num_uservals(self._h)):
+            info = UservalInfo()
+            lib().mmhip_filter_userval_info(self._h, i, C.byref(info))
+            out.append(dict(kind=info.kind, index=info.index, name=info.name.decode(),
+                            int_min=info.int_min, int_max=info.int_max, int_default=info.int_default,
+                            float_min=info.float_min, float_max=info.float_max, float_default=info.float_default,
+                            bool_default=info.bool_default, image_flags=info.image_flags))
+        return out
+
+    @property
+    def ir(self):
+        return json.loads(lib().mmhip_filter_ir_json(self._h).decode())
+
+    @property
+    def ir_json(self):
+        return lib().mmhip_filter_ir_json(self._h).decode()
+
+    @property
+    def kernel_source(self):
+        return lib().mmhip_filter_kernel_source(self._h).decode()
+
+    @property
+    def num_native_calls(self):
+        return lib().mmhip_filter_num_native_calls(self._h)
+
+    def jit(self, load=False):
+        """hiprtc-compiles the kernel string for gfx950; returns the code-object size."""
+        n = lib().mmhip_filter_jit(self._h, 1 if load else 0)
+        if n < 0:
+            raise MathMapError(_err())
+        return n
+
+    @property
+    def jit_seconds(self):
+        return lib().mmhip_filter_jit_seconds(self._h)
+
+    def invoke(self, width, height):
+        return Invocation(self, width, height)
+
+
+class Invocation:
+    """A filter bound to a canvas size, user values and input images (all in HBM)."""
+
+    def __init__(self, flt, width, height):
+        self.filter = flt
+        self.width, self.height = width, height
+        self._h = lib().mmhip_invoke(flt._h, width, height)
+        if not self._h:
+            raise MathMapError(_err())
+        self._keep = []
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().mmhip_invocation_free(h)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MathMapError(_err())
+
+    def _index(self, name):
+        for u in self.filter.uservals:
+            if u["name"] == name:
+                return u
+        raise MathMapError("filter has no user value `%s'" % name)
+
+    def set(self, name, value):
+        """Sets a user value by name (the CLI's -Dname=value)."""
+        u = self._index(name)
+        k, i = u["kind"], u["index"]
+        if k == UV_INT:
+            self._check(lib().mmhip_set_int(self._h, i, int(value)))
+        elif k == UV_FLOAT:
+            self._check(lib().mmhip_set_float(self._h, i, float(value)))
+        elif k == UV_BOOL:
+            self._check(lib().mmhip_set_bool(self._h, i, int(bool(value))))
+        elif k == UV_COLOR:
+            r, g, b, a = value
+            self._check(lib().mmhip_set_color(self._h, i, r, g, b, a))
+        elif k == UV_IMAGE:
+            self.set_image(name, value)
+        else:
+            raise MathMapError("cannot set user value `%s'" % name)
+
+    def set_image(self, name, array):
+        """Binds a host uint8 array [H,W,3|4] as input drawable (uploaded once to HBM)."""
+        u = self._index(name)
+        a = np.ascontiguousarray(array, dtype=np.uint8)
+        h, w, c = a.shape
+        self._check(lib().mmhip_set_image_host(self._h, u["index"], a.ctypes.data_as(C.c_void_p), w, h, c))
+
+    def set_image_device(self, name, device_ptr, width, height, keepalive=None):
+        """Binds a packed 0xRRGGBBAA uint32 image already resident in HBM."""
+        u = self._index(name)
+        if keepalive is not None:
+            self._keep.append(keepalive)
+        self._check(lib().mmhip_set_image_device(self._h, u["index"], C.c_void_p(device_ptr), width, height))
+
+    def set_edge_colors(self, cx, cy):
+        self._check(lib().mmhip_set_edge_colors(self._h, cx, cy))
+
+    def enable_timing(self, on=True):
+        self._check(lib().mmhip_enable_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        return lib().mmhip_last_kernel_ms(self._h)
+
+    def render(self, t=0.0, frame=0):
+        """Renders the whole frame and returns it as a uint8 [H,W,4] array (RGBA)."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(lib().mmhip_render_host(self._h, frame, t, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def render_rows(self, out_ptr, first_row, last_row, t=0.0, frame=0, row_stride=None, bpp=4, floatmap=False,
+                    stream=0, region=None):
+        """Asynchronously renders rows [first_row,last_row) into device memory at out_ptr
+        (the reference's calc_lines band, mathmap_common.c:837-846)."""
+        rx, ry, rw, rh = region if region is not None else (0, 0, self.width, self.height)
+        if row_stride is None:
+            row_stride = rw * bpp
+        self._check(lib().mmhip_render(self._h, frame, t, rx, ry, rw, rh, first_row, last_row, C.c_void_p(out_ptr),
+                                       row_stride, bpp, 1 if floatmap else 0, C.c_void_p(stream)))
+
+    def sync(self):
+        self._check(lib().mmhip_sync(self._h))
+
+
+def device_count():
+    return lib().mmhip_device_count()

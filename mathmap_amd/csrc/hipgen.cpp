@@ -1,0 +1,428 @@
+// IR -> HIP C++ source.  See hipgen.h.
+//
+// Shape of the generated translation unit:
+//
+//   #define MM_INTERSAMPLE ...           (specialisation constants)
+//   <mm_device.h>                        (device runtime)
+//   extern "C" __global__ void mm_prologue(mm_args A, char *XY)      one lane: frame-constant
+//                                                                    values -> constant buffer,
+//                                                                    native-filter call records
+//   extern "C" __global__ void mm_pixels(mm_args A, const char *XY)  one work-item per output pixel
+//
+// Statement printing follows the reference's backends/cc.c:192-397 (one C variable
+// per SSA value, phi copies at the end of branches / loop bodies), so the arithmetic
+// the GPU executes is statement-for-statement the arithmetic gcc compiled for the
+// cc backend.
+#include "hipgen.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+
+#include "front.h"
+
+namespace mm {
+
+namespace {
+
+enum Slice { PROLOGUE, PIXEL };
+
+struct Generator {
+    FilterCode &code;
+    const KernelOptions &opt;
+    std::ostringstream out;
+    KernelSource ks;
+    std::map<Value *, int> transfer_off;       // hoisted values read by the pixel kernel
+    std::vector<Value *> transfer_order;
+    std::map<const Stmt *, int> native_index;
+
+    Generator(FilterCode &c, const KernelOptions &o) : code(c), opt(o) {}
+
+    static std::string vname(const Value *v) {
+        char buf[64];
+        snprintf(buf, sizeof buf, "v%d_%d", v->var->id, v->index);
+        return buf;
+    }
+
+    static std::string ctype(const CompVar *v) {
+        switch (v->type) {
+            case Ty::Int: return "int";
+            case Ty::Float: return "float";
+            case Ty::Complex: return "mm_complex";
+            case Ty::Color: return "color_t";
+            case Ty::Curve:
+            case Ty::Gradient: return "int";
+            case Ty::Image: return "mm_image";
+            case Ty::Tuple: return "mm_tup<" + std::to_string(v->tuple_len > 0 ? v->tuple_len : 4) + ">";
+            default: throw CompileError(std::string("HIP backend: unsupported variable type ") + ty_name(v->type));
+        }
+    }
+
+    static int type_size(const CompVar *v) {
+        switch (v->type) {
+            case Ty::Complex: return 8;
+            case Ty::Image: return 24;
+            case Ty::Tuple: return 4 * (v->tuple_len > 0 ? v->tuple_len : 4);
+            default: return 4;
+        }
+    }
+
+    static std::string float_literal(float f) {
+        if (std::isnan(f)) return "__builtin_nan(\"\")";
+        if (std::isinf(f)) return f > 0 ? "(1.0/0.0)" : "(-1.0/0.0)";
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.17g", (double)f);
+        std::string s = buf;
+        if (s.find_first_of(".en") == std::string::npos) s += ".0";
+        return s;
+    }
+
+    std::string prim(const Primary &p, Slice) {
+        switch (p.kind) {
+            case Primary::Val: {
+                const Value *v = p.value;
+                if (v->index < 0) {
+                    switch (v->var->type) {
+                        case Ty::Image: return "UNINITED_IMAGE";
+                        case Ty::Complex: return "mm_cmake(0.0f, 0.0f)";
+                        case Ty::Tuple: return ctype(v->var) + "{}";
+                        default: return "0";
+                    }
+                }
+                return vname(v);
+            }
+            case Primary::IntConst: return p.i < 0 ? "(" + std::to_string(p.i) + ")" : std::to_string(p.i);
+            case Primary::FloatConst: {
+                std::string s = float_literal(p.f);
+                return s[0] == '-' ? "(" + s + ")" : s;
+            }
+            case Primary::ComplexConst: return "COMPLEX(" + float_literal(p.f) + "," + float_literal(p.f2) + ")";
+            case Primary::ColorConst: return std::to_string(p.color) + "u";
+            default: return "0";
+        }
+    }
+
+    static const char *libm_name(const char *cname) {
+        static const std::pair<const char *, const char *> table[] = {
+            {"sqrt", "mm_sqrt"}, {"hypot", "mm_hypot"}, {"sin", "mm_sin"}, {"cos", "mm_cos"}, {"tan", "mm_tan"},
+            {"asin", "mm_asin"}, {"acos", "mm_acos"}, {"atan", "mm_atan"}, {"atan2", "mm_atan2"}, {"pow", "mm_pow"},
+            {"exp", "mm_exp"}, {"log", "mm_log"}, {"sinh", "mm_sinh"}, {"cosh", "mm_cosh"}, {"tanh", "mm_tanh"},
+            {"asinh", "mm_asinh"}, {"acosh", "mm_acosh"}, {"atanh", "mm_atanh"}, {"fabs", "mm_fabs"},
+            {"floor", "mm_floor"}, {"ceil", "mm_ceil"}, {"GAMMA", "mm_gamma"}, {"gsl_sf_beta", "mm_beta"}};
+        for (auto &t : table)
+            if (!strcmp(t.first, cname)) return t.second;
+        return nullptr;
+    }
+
+    std::string rhs(const Rhs &r, Slice sl, const Stmt *stmt, const CompVar *lhs) {
+        switch (r.kind) {
+            case Rhs::Prim: return prim(r.prim, sl);
+            case Rhs::Internal: return r.internal;
+            case Rhs::Tuple: {
+                std::string s = "mm_tup<" + std::to_string(r.args.size()) + ">{{";
+                for (size_t i = 0; i < r.args.size(); ++i) s += (i ? ", (float)(" : "(float)(") + prim(r.args[i], sl) + ")";
+                return s + "}}";
+            }
+            case Rhs::Closure: {
+                if (r.filter->kind == Filter::MathMap) return "mm_closure_image(A)";
+                auto it = native_index.find(stmt);
+                if (it == native_index.end() || sl != PROLOGUE)
+                    throw CompileError("native filter `" + r.filter->name +
+                                       "' is called with pixel-dependent arguments; the HIP backend needs them frame-constant");
+                int k = it->second;
+                std::string s = "mm_native_call(A, XY + " + std::to_string(ks.natives[k].record_offset) + ", " +
+                                std::to_string(k) + ", " + std::to_string(r.args.size());
+                for (size_t i = 0; i < r.args.size(); ++i) s += ", mm_narg(" + prim(r.args[i], sl) + ")";
+                for (size_t i = r.args.size(); i < 4; ++i) s += ", mm_narg(0)";
+                return s + ")";
+            }
+            case Rhs::FilterCall: throw CompileError("HIP backend: non-inlined filter calls are not supported");
+            case Rhs::Op: {
+                const char *cn = r.op->cname;
+                if (!strcmp(cn, "RENDER")) {
+                    auto it = native_index.find(stmt);
+                    if (it == native_index.end() || sl != PROLOGUE)
+                        throw CompileError("render() needs frame-constant arguments in the HIP backend");
+                    int k = it->second;
+                    return "mm_native_call(A, XY + " + std::to_string(ks.natives[k].record_offset) + ", " +
+                           std::to_string(k) + ", 3, mm_narg(" + prim(r.args[0], sl) + "), mm_narg(" + prim(r.args[1], sl) +
+                           "), mm_narg(" + prim(r.args[2], sl) + "), mm_narg(0))";
+                }
+                for (const char *bad : {"RAND", "ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P",
+                                        "ELL_INT_D", "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ", "ELL_JAC",
+                                        "SOLVE_LINEAR_2", "SOLVE_LINEAR_3", "SOLVE_POLY_2", "SOLVE_POLY_3",
+                                        "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH", "START_DEBUG_TUPLE",
+                                        "SET_DEBUG_TUPLE_DATA", "OUTPUT_TUPLE"})
+                    if (!strcmp(cn, bad)) throw CompileError(std::string("HIP backend: op ") + cn + " is not supported yet");
+                if (!strcmp(cn, "PRINT_FLOAT") || !strcmp(cn, "NEWLINE")) return "0";
+                std::string name = cn;
+                if (const char *lm = libm_name(cn)) name = lm;
+                // exact f32 fast path: (float)sqrt((double)f) == sqrtf(f), correctly rounded
+                if (opt.fast_math_exact && !strcmp(cn, "sqrt") && lhs && lhs->type == Ty::Float &&
+                    r.args[0].type() == Ty::Float)
+                    name = "mm_sqrt_f32";
+                std::string s = name + "(";
+                for (size_t i = 0; i < r.args.size(); ++i) s += (i ? "," : "") + prim(r.args[i], sl);
+                return s + ")";
+            }
+            default: return "0";
+        }
+    }
+
+    // ---- which values live where -------------------------------------------------------
+    void collect_values(Block &b, Slice sl, std::vector<Value *> &defs, std::set<Value *> &uses) {
+        auto use = [&](const Rhs &r) {
+            if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val) uses.insert(r.prim.value);
+            for (const Primary &p : r.args)
+                if (p.kind == Primary::Val) uses.insert(p.value);
+        };
+        for (Stmt *s : b) {
+            bool mine = sl == PROLOGUE ? s->hoisted : s->in_pixel;
+            if (!mine) continue;
+            switch (s->kind) {
+                case Stmt::Assign: defs.push_back(s->lhs); use(s->rhs); break;
+                case Stmt::Phi: defs.push_back(s->lhs); use(s->rhs); use(s->rhs2); break;
+                case Stmt::If:
+                    use(s->cond);
+                    collect_values(s->then_, sl, defs, uses);
+                    collect_values(s->else_, sl, defs, uses);
+                    collect_values(s->phis, sl, defs, uses);
+                    break;
+                case Stmt::While:
+                    collect_values(s->phis, sl, defs, uses);
+                    use(s->cond);
+                    collect_values(s->body, sl, defs, uses);
+                    break;
+                default: break;
+            }
+        }
+    }
+
+    void find_natives(Block &b) {
+        for (Stmt *s : b) {
+            if (s->kind == Stmt::Assign) {
+                bool native = (s->rhs.kind == Rhs::Closure && s->rhs.filter->kind == Filter::Native) ||
+                              (s->rhs.kind == Rhs::Op && !strcmp(s->rhs.op->cname, "RENDER"));
+                if (native) {
+                    NativeCall nc;
+                    nc.func = s->rhs.kind == Rhs::Closure ? s->rhs.filter->native_func : "RENDER";
+                    for (const Primary &p : s->rhs.args) nc.arg_types.push_back(p.type());
+                    native_index[s] = (int)ks.natives.size();
+                    ks.natives.push_back(nc);
+                }
+            } else if (s->kind == Stmt::If) {
+                find_natives(s->then_);
+                find_natives(s->else_);
+            } else if (s->kind == Stmt::While)
+                find_natives(s->body);
+        }
+    }
+
+    // ---- statement printing ------------------------------------------------------------------
+    void phis(Block &list, int branch, Slice sl, const std::string &ind) {
+        std::vector<Stmt *> mine;
+        for (Stmt *p : list) {
+            if (p->kind != Stmt::Phi) continue;
+            if (!(sl == PROLOGUE ? p->hoisted : p->in_pixel)) continue;
+            const Rhs &r = branch == 0 ? p->rhs : p->rhs2;
+            if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val && r.prim.value == p->lhs) continue;
+            mine.push_back(p);
+        }
+        // phis are parallel copies: if a source is the target of another copy in the
+        // list, go through temporaries
+        std::set<Value *> targets;
+        for (Stmt *p : mine) targets.insert(p->lhs);
+        bool hazard = false;
+        for (Stmt *p : mine) {
+            const Rhs &r = branch == 0 ? p->rhs : p->rhs2;
+            if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val && targets.count(r.prim.value)) hazard = true;
+        }
+        if (!hazard) {
+            for (Stmt *p : mine)
+                out << ind << vname(p->lhs) << " = " << rhs(branch == 0 ? p->rhs : p->rhs2, sl, p, p->lhs->var) << ";\n";
+            return;
+        }
+        out << ind << "{\n";
+        for (size_t i = 0; i < mine.size(); ++i)
+            out << ind << "  " << ctype(mine[i]->lhs->var) << " pc" << i << " = "
+                << rhs(branch == 0 ? mine[i]->rhs : mine[i]->rhs2, sl, mine[i], mine[i]->lhs->var) << ";\n";
+        for (size_t i = 0; i < mine.size(); ++i) out << ind << "  " << vname(mine[i]->lhs) << " = pc" << i << ";\n";
+        out << ind << "}\n";
+    }
+
+    void stmts(Block &b, Slice sl, const std::string &ind) {
+        for (Stmt *s : b) {
+            bool mine = sl == PROLOGUE ? s->hoisted : s->in_pixel;
+            if (!mine) continue;
+            switch (s->kind) {
+                case Stmt::Assign:
+                    out << ind << vname(s->lhs) << " = " << rhs(s->rhs, sl, s, s->lhs->var) << ";\n";
+                    break;
+                case Stmt::If:
+                    out << ind << "if (" << rhs(s->cond, sl, s, nullptr) << ") {\n";
+                    stmts(s->then_, sl, ind + "  ");
+                    phis(s->phis, 0, sl, ind + "  ");
+                    out << ind << "} else {\n";
+                    stmts(s->else_, sl, ind + "  ");
+                    phis(s->phis, 1, sl, ind + "  ");
+                    out << ind << "}\n";
+                    break;
+                case Stmt::While:
+                    phis(s->phis, 0, sl, ind);
+                    out << ind << "while (" << rhs(s->cond, sl, s, nullptr) << ") {\n";
+                    stmts(s->body, sl, ind + "  ");
+                    phis(s->phis, 1, sl, ind + "  ");
+                    out << ind << "}\n";
+                    break;
+                default: break;
+            }
+        }
+    }
+
+    void decls(const std::vector<Value *> &defs, const std::string &ind) {
+        std::set<Value *> seen;
+        for (Value *v : defs) {
+            if (v->index < 0 || !seen.insert(v).second) continue;
+            out << ind << ctype(v->var) << " " << vname(v) << ";\n";
+        }
+    }
+
+    static unsigned long long fnv(const std::string &s) {
+        unsigned long long h = 1469598103934665603ull;
+        for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+        return h;
+    }
+
+    void run() {
+        analyze_and_layout();
+        emit_source();
+    }
+
+    std::vector<Value *> pro_defs, pix_defs;
+    std::set<Value *> pro_uses, pix_uses;
+
+    void analyze_and_layout() {
+        find_natives(code.body);
+        collect_values(code.body, PROLOGUE, pro_defs, pro_uses);
+        collect_values(code.body, PIXEL, pix_defs, pix_uses);
+        for (int i = 0; i < 4; ++i) pix_uses.insert(code.result[i]);
+        std::set<Value *> pix_def_set(pix_defs.begin(), pix_defs.end());
+        int off = 0;
+        // native call records first (fixed layout the host can parse)
+        for (NativeCall &nc : ks.natives) {
+            nc.record_offset = off;
+            off += MM_NATIVE_REC_BYTES;
+        }
+        for (Value *v : pro_defs) {
+            if (!pix_uses.count(v) || pix_def_set.count(v) || transfer_off.count(v)) continue;
+            int sz = type_size(v->var);
+            int align = sz >= 8 ? 8 : 4;
+            off = (off + align - 1) / align * align;
+            transfer_off[v] = off;
+            transfer_order.push_back(v);
+            off += sz;
+        }
+        ks.xy_bytes = (off + 15) / 16 * 16;
+        if (ks.xy_bytes == 0) ks.xy_bytes = 16;
+        ks.has_prologue = !pro_defs.empty();
+        // a value used by the pixel slice must be defined there or transferred
+        for (Value *v : pix_uses)
+            if (v && v->index >= 0 && !pix_def_set.count(v) && !transfer_off.count(v))
+                throw CompileError("internal: value " + vname(v) + " used in the pixel kernel but defined nowhere");
+    }
+
+    void emit_source() {
+        int tw = opt.tile_w;
+        if (tw != 8 && tw != 16 && tw != 32 && tw != 64 && tw != 128 && tw != 256) tw = 16;
+        ks.tile_w = tw;
+        ks.tile_h = 256 / tw;
+        out << "#define MM_INTERSAMPLE " << opt.intersample << "\n";
+        out << "#define MM_SUPERSAMPLING " << opt.supersampling << "\n";
+        out << "#define MM_EDGE_X " << opt.edge_x << "\n#define MM_EDGE_Y " << opt.edge_y << "\n";
+        out << "#define MM_TILE_W " << ks.tile_w << "\n#define MM_TILE_H " << ks.tile_h << "\n";
+        out << device_prelude() << "\n";
+        out << R"(
+MM_DEV mm_image mm_closure_image(const mm_args &A) {
+    mm_image im; im.idx = -1; im.pw = A.img_width; im.ph = A.img_height; im.xf = im.yf = 1.0f; im.resized = 0; return im;
+}
+struct mm_narg_t { int kind; int i; float f; mm_image img; };
+MM_DEV mm_narg_t mm_narg(int v) { mm_narg_t a; a.kind = 0; a.i = v; a.f = (float)v; a.img = mm_null_image(); return a; }
+MM_DEV mm_narg_t mm_narg(float v) { mm_narg_t a; a.kind = 1; a.i = (int)v; a.f = v; a.img = mm_null_image(); return a; }
+MM_DEV mm_narg_t mm_narg(double v) { return mm_narg((float)v); }
+MM_DEV mm_narg_t mm_narg(mm_image v) { mm_narg_t a; a.kind = 2; a.i = v.idx; a.f = 0.0f; a.img = v; return a; }
+// Records a native-filter call for the host (which runs the filter's kernels between
+// the prologue and the pixel kernel) and returns the handle of its result float map.
+MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm_narg_t a0, mm_narg_t a1, mm_narg_t a2, mm_narg_t a3) {
+    int *hdr = (int *)rec;
+    hdr[0] = 1; hdr[1] = k; hdr[2] = nargs; hdr[3] = 0;
+    mm_narg_t *args = (mm_narg_t *)(rec + 16);
+    args[0] = a0; args[1] = a1; args[2] = a2; args[3] = a3;
+    mm_image im; im.idx = A.native_slot_base + k; im.pw = A.render_width; im.ph = A.render_height;
+    im.xf = im.yf = 1.0f; im.resized = 0;
+    return im;
+}
+#define MM_INTERNALS \
+    const float t = A.t; const float R = A.R; const int frame = A.frame; \
+    const int __canvasPixelW = A.img_width, __canvasPixelH = A.img_height; \
+    const int __renderPixelW = A.render_width, __renderPixelH = A.render_height; \
+    (void)t; (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;
+)";
+        // ---- prologue ----
+        ks.prologue_name = "mm_prologue";
+        ks.pixel_name = "mm_pixels";
+        out << "extern \"C\" __global__ void mm_prologue(mm_args A, char *XY) {\n";
+        out << "  if (blockIdx.x != 0 || threadIdx.x != 0) return;\n  MM_INTERNALS\n";
+        decls(pro_defs, "  ");
+        stmts(code.body, PROLOGUE, "  ");
+        for (Value *v : transfer_order)
+            out << "  *(" << ctype(v->var) << " *)(XY + " << transfer_off[v] << ") = " << vname(v) << ";\n";
+        out << "}\n\n";
+        // ---- pixel kernel ----
+        out << R"(extern "C" __global__ void __launch_bounds__(256) mm_pixels(mm_args A, const char *__restrict__ XY) {
+  MM_INTERNALS
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs; give each
+  // XCD one contiguous band of tiles so neighbouring gathers share its L2.
+  const int tiles_x = (A.region_width + MM_TILE_W - 1) / MM_TILE_W;
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = bid >> 3;
+  const int per = nwg >> 3, rem = nwg & 7;
+  const int swz = xcd * per + (xcd < rem ? xcd : rem) + q;
+  const int tile_y = swz / tiles_x, tile_x = swz - tile_y * tiles_x;
+  const int col = tile_x * MM_TILE_W + (threadIdx.x % MM_TILE_W);
+  const int rl = tile_y * MM_TILE_H + (threadIdx.x / MM_TILE_W);   // row within this launch
+  if (col >= A.region_width || rl >= A.num_rows) return;
+  const int row = A.first_row + rl;                                 // absolute row
+  const float y = CALC_VIRTUAL_Y(row, A.frame_render_height, A.sampling_offset_y);
+  const float x = CALC_VIRTUAL_X(col + A.region_x, A.frame_render_width, A.sampling_offset_x);
+  (void)x; (void)y;
+)";
+        for (Value *v : transfer_order)
+            out << "  const " << ctype(v->var) << " " << vname(v) << " = *(const " << ctype(v->var) << " *)(XY + "
+                << transfer_off[v] << ");\n";
+        decls(pix_defs, "  ");
+        stmts(code.body, PIXEL, "  ");
+        out << "  mm_tup<4> rt;\n";
+        for (int i = 0; i < 4; ++i) out << "  rt.v[" << i << "] = " << prim(Primary::V(code.result[i]), PIXEL) << ";\n";
+        out << "  mm_store_pixel(A, rl, col, rt);\n}\n";
+        ks.source = out.str();
+        char buf[32];
+        snprintf(buf, sizeof buf, "%016llx", fnv(ks.source));
+        ks.key = buf;
+    }
+};
+
+}  // namespace
+
+KernelSource generate_hip(FilterCode &code, const KernelOptions &opt) {
+    Generator g(code, opt);
+    g.run();
+    return std::move(g.ks);
+}
+
+}  // namespace mm

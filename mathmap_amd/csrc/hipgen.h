@@ -1,0 +1,42 @@
+// IR -> HIP C++ kernel string.  The MI355X counterpart of the reference's
+// backends/cc.c (which fills new_template.c.in and shells out to gcc).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "ir.h"
+
+namespace mm {
+
+struct KernelOptions {
+    int intersample = 1;      // bilinear input fetch (CLI flag -i)
+    int supersampling = 0;
+    int edge_x = 0, edge_y = 0;
+    int tile_w = 16;          // pixels per workgroup row; tile_h = 256 / tile_w
+    bool hoist = true;        // evaluate frame-constant code once per frame in a prologue kernel
+    bool fast_math_exact = true;   // use f32 paths only where bit-identical to the double path
+};
+
+// One native-filter (or render) call found in the frame-constant code.
+struct NativeCall {
+    std::string func;             // "native_filter_gaussian_blur", "RENDER", ...
+    std::vector<Ty> arg_types;
+    int record_offset = 0;        // byte offset of its record in the frame-constant buffer
+};
+
+enum { MM_NATIVE_REC_BYTES = 320, MM_NATIVE_ARG_BYTES = 32, MM_NATIVE_MAX_ARGS = 9 };
+
+struct KernelSource {
+    std::string source;           // full translation unit (prelude + 2 kernels)
+    std::string prologue_name, pixel_name;
+    int xy_bytes = 0;             // size of the frame-constant buffer
+    bool has_prologue = false;
+    std::vector<NativeCall> natives;
+    int tile_w = 16, tile_h = 16;
+    std::string key;              // cache key (hash of source)
+};
+
+KernelSource generate_hip(FilterCode &code, const KernelOptions &opt);
+const char *device_prelude();
+
+}  // namespace mm

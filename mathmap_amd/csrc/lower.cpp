@@ -1,0 +1,510 @@
+// Typed expression tree -> structured SSA IR, with every non-recursive filter call
+// inlined and MathMap closures applied at compile time.
+//
+// Behavioural spec: compiler.c:1715-1773 (image resize factors), :1875-2227
+// (gen_code), :2338-2511 (coordinate / limit / r,a bindings), :2610-2664
+// (gen_filter_code).  The reference reaches the same code shape through its
+// closure-application + inlining + copy-propagation passes (compiler.c:4702-4764);
+// here application happens directly while lowering, because the image operand's
+// definition chain is already known in SSA form.
+#include <cassert>
+#include <cmath>
+#include <map>
+
+#include "front.h"
+#include "gen.h"
+
+namespace mm {
+
+namespace {
+
+struct Env {
+    Filter *filter = nullptr;
+    FilterVars *vars = nullptr;
+    std::map<std::string, Value *> internals;
+    std::map<int, Value *> uservals;
+    Env *parent = nullptr;
+};
+
+struct ImageChain {
+    // resolved base of an image value plus the resize factors applied on top of it
+    enum Base { Unknown, MathMapClosure, Runtime } base = Unknown;
+    Stmt *closure_def = nullptr;
+    std::vector<std::pair<Primary, Primary>> factors;   // outermost first
+};
+
+class Lowerer {
+   public:
+    Lowerer(Module &m, FilterCode &code) : m_(m), code_(code), g_(code) {}
+    void run(Filter *f);
+
+   private:
+    Module &m_;
+    FilterCode &code_;
+    Gen g_;
+    Env *env_ = nullptr;
+    std::vector<Filter *> inlining_;
+
+    bool needs_xy_scaling(unsigned flags) const {
+        return (flags & (IMAGE_FLAG_UNIT | IMAGE_FLAG_SQUARE)) != IMAGE_FLAG_UNIT;
+    }
+
+    Value *internal_value(const std::string &name, bool allow_bindings);
+    void bind_internal(const std::string &name, Rhs rhs, Ty ty = Ty::Int);
+    Value *resize_image_if_necessary(Primary image, unsigned flags);
+    void gen_limit_bindings();
+    void gen_xy_bindings(Value *x, Value *y);
+    void gen_ra_bindings();
+    void gen_filter(Filter *f, const std::vector<Primary> *args, CompVar *result[4]);
+
+    void gen(AstNode *n, CompVar **dest, bool alloced);
+    std::vector<CompVar *> gen_new(AstNode *n) {
+        std::vector<CompVar *> d(n->result.len, nullptr);
+        gen(n, d.data(), false);
+        return d;
+    }
+    void gen_func(AstNode *n, CompVar **dest, bool alloced);
+    void gen_closure(AstNode *n, CompVar **dest, bool alloced);
+    bool single_const(AstNode *n, int *iv);
+    ImageChain resolve_image(Value *v);
+    void alloc_var(Variable *v);
+    void reset_vars(FilterVars *fv);
+};
+
+Value *Lowerer::internal_value(const std::string &name, bool allow_bindings) {
+    if (allow_bindings) {
+        auto it = env_->internals.find(name);
+        if (it != env_->internals.end()) return it->second;
+    }
+    CompVar *t = g_.temp();
+    return g_.assign(t, Rhs::Int(name));
+}
+
+void Lowerer::bind_internal(const std::string &name, Rhs rhs, Ty ty) {
+    CompVar *t = g_.temp(ty);
+    env_->internals[name] = g_.assign(t, std::move(rhs));
+}
+
+// compiler.c:1715-1773
+Value *Lowerer::resize_image_if_necessary(Primary image, unsigned flags) {
+    CompVar *resized = g_.temp(Ty::Image);
+    if (!needs_xy_scaling(flags)) return g_.assign(resized, Rhs::P(image));
+    CompVar *pw = g_.temp(), *ph = g_.temp(), *xf = g_.temp(), *yf = g_.temp();
+    g_.assign_op(pw, "IMAGE_PIXEL_WIDTH", {image});
+    g_.assign_op(ph, "IMAGE_PIXEL_HEIGHT", {image});
+    if (flags == 0) {
+        g_.assign_op(xf, "DIV", {Primary::I(2), g_.P(pw)});
+        g_.assign_op(yf, "DIV", {Primary::I(2), g_.P(ph)});
+    } else {
+        CompVar *mx = g_.temp();
+        g_.assign_op(mx, "MAX", {g_.P(pw), g_.P(ph)});
+        g_.assign_op(xf, "DIV", {g_.P(mx), g_.P(pw)});
+        g_.assign_op(yf, "DIV", {g_.P(mx), g_.P(ph)});
+    }
+    g_.assign_op(resized, "STRIP_RESIZE", {image});
+    return g_.assign_op(resized, "RESIZE_IMAGE", {g_.P(resized), g_.P(xf), g_.P(yf)});
+}
+
+// compiler.c:2338-2403
+void Lowerer::gen_limit_bindings() {
+    unsigned fl = env_->filter->flags & (IMAGE_FLAG_UNIT | IMAGE_FLAG_SQUARE);
+    if (fl == 0) {
+        bind_internal("W", Rhs::V(internal_value("__canvasPixelW", false)));
+        bind_internal("H", Rhs::V(internal_value("__canvasPixelH", false)));
+        for (auto p : {std::pair<const char *, const char *>{"X", "__canvasPixelW"}, {"Y", "__canvasPixelH"}}) {
+            CompVar *m1 = g_.temp();
+            g_.assign_op(m1, "SUB", {Primary::V(internal_value(p.second, true)), Primary::I(1)});
+            bind_internal(p.first, Rhs::O(g_.op("DIV", 2), {g_.P(m1), Primary::I(2)}));
+        }
+    } else if (fl == IMAGE_FLAG_UNIT) {
+        bind_internal("W", Rhs::I(2));
+        bind_internal("H", Rhs::I(2));
+        bind_internal("X", Rhs::I(1));
+        bind_internal("Y", Rhs::I(1));
+    } else {
+        CompVar *mx = g_.temp();
+        g_.assign_op(mx, "MAX", {Primary::V(internal_value("__canvasPixelW", false)),
+                                 Primary::V(internal_value("__canvasPixelH", false))});
+        Value *mxv = mx->current;
+        bind_internal("X", Rhs::O(g_.op("DIV", 2), {Primary::V(internal_value("__canvasPixelW", false)), Primary::V(mxv)}));
+        Value *xv = env_->internals["X"];
+        bind_internal("Y", Rhs::O(g_.op("DIV", 2), {Primary::V(internal_value("__canvasPixelH", false)), Primary::V(mxv)}));
+        Value *yv = env_->internals["Y"];
+        bind_internal("W", Rhs::O(g_.op("MUL", 2), {Primary::V(xv), Primary::I(2)}));
+        bind_internal("H", Rhs::O(g_.op("MUL", 2), {Primary::V(yv), Primary::I(2)}));
+    }
+}
+
+// compiler.c:2405-2420
+void Lowerer::gen_xy_bindings(Value *x, Value *y) {
+    bind_internal("x", Rhs::O(g_.op("MUL", 2), {Primary::V(x), Primary::V(internal_value("X", true))}));
+    bind_internal("y", Rhs::O(g_.op("MUL", 2), {Primary::V(y), Primary::V(internal_value("Y", true))}));
+}
+
+// compiler.c:2467-2511
+void Lowerer::gen_ra_bindings() {
+    CompVar *r = g_.temp(Ty::Float), *a = g_.temp(Ty::Float), *xr = g_.temp(Ty::Float);
+    Value *x = internal_value("x", true);
+    Value *y = internal_value("y", true);
+    g_.assign_op(r, "hypot", {Primary::V(x), Primary::V(y)});
+    g_.start_if(Rhs::O(g_.op("EQ", 2), {g_.P(r), Primary::F(0.0f)}));
+    g_.assign(a, Rhs::F(0.0f));
+    g_.switch_branch();
+    g_.assign_op(xr, "DIV", {Primary::V(x), g_.P(r)});
+    g_.assign_op(a, "acos", {g_.P(xr)});
+    g_.end_if();
+    g_.start_if(Rhs::O(g_.op("LESS", 2), {Primary::V(y), Primary::F(0.0f)}));
+    g_.assign_op(a, "SUB", {Primary::F((float)(2 * M_PI)), g_.P(a)});
+    g_.switch_branch();
+    g_.end_if();
+    bind_internal("r", Rhs::V(r->current), Ty::Float);
+    bind_internal("a", Rhs::V(a->current), Ty::Float);
+}
+
+void Lowerer::reset_vars(FilterVars *fv) {
+    for (auto &v : fv->vars) v->compvar.assign(v->type.len, nullptr);
+}
+
+void Lowerer::alloc_var(Variable *v) {
+    for (int i = 0; i < v->type.len; ++i)
+        if (!v->compvar[i]) {
+            bool is_image = v->type.tag == m_.tags.image && v->type.len == 1;
+            v->compvar[i] = code_.new_var(is_image ? Ty::Image : Ty::Int, v->name, i);
+        }
+}
+
+// compiler.c:2610-2664.  `args` = closure arguments followed by x, y, t for an
+// inlined call; nullptr for the main filter.
+void Lowerer::gen_filter(Filter *f, const std::vector<Primary> *args, CompVar *result[4]) {
+    for (Filter *h : inlining_)
+        if (h == f) throw CompileError("recursive filter `" + f->name + "' is not supported by the HIP backend yet");
+    inlining_.push_back(f);
+    Env env;
+    env.filter = f;
+    env.vars = m_.vars[f].get();
+    env.parent = env_;
+    // variables are per-activation: save the callee's compvars (it may be active
+    // further up the inlining stack under a different name) and start fresh
+    std::vector<std::vector<CompVar *>> saved;
+    for (auto &v : env.vars->vars) saved.push_back(v->compvar);
+    reset_vars(env.vars);
+    env_ = &env;
+
+    gen_limit_bindings();
+    if (args) {
+        int n = (int)args->size();
+        int nuv = (int)f->uservals.size();
+        assert(n == nuv + 3);
+        for (int i = 0; i < nuv; ++i) {
+            const UservalInfo &u = f->uservals[i];
+            Ty ty = u.kind == UvKind::Float ? Ty::Float : u.kind == UvKind::Color ? Ty::Color
+                  : u.kind == UvKind::Curve ? Ty::Curve : u.kind == UvKind::Gradient ? Ty::Gradient
+                  : u.kind == UvKind::Image ? Ty::Image : Ty::Int;
+            CompVar *bv = g_.temp(ty);
+            if (u.kind == UvKind::Image)
+                env.uservals[i] = g_.assign(bv, Rhs::V(resize_image_if_necessary((*args)[i], u.image_flags)));
+            else
+                env.uservals[i] = g_.assign(bv, Rhs::P((*args)[i]));
+        }
+        CompVar *xt = g_.temp(), *yt = g_.temp();
+        g_.assign(xt, Rhs::P((*args)[n - 3]));
+        g_.assign(yt, Rhs::P((*args)[n - 2]));
+        gen_xy_bindings(xt->current, yt->current);
+        bind_internal("t", Rhs::P((*args)[n - 1]));
+    } else {
+        static const char *getters[] = {"USERVAL_INT_ACCESS", "USERVAL_FLOAT_ACCESS", "USERVAL_BOOL_ACCESS",
+                                        "USERVAL_COLOR_ACCESS", "USERVAL_CURVE_ACCESS", "USERVAL_GRADIENT_ACCESS",
+                                        "USERVAL_IMAGE_ACCESS"};
+        for (const UservalInfo &u : f->uservals) {
+            Ty ty = u.kind == UvKind::Float ? Ty::Float : u.kind == UvKind::Color ? Ty::Color
+                  : u.kind == UvKind::Curve ? Ty::Curve : u.kind == UvKind::Gradient ? Ty::Gradient
+                  : u.kind == UvKind::Image ? Ty::Image : Ty::Int;
+            if (u.kind == UvKind::Image) {
+                CompVar *img = g_.temp(Ty::Image);
+                g_.assign_op(img, "USERVAL_IMAGE_ACCESS", {Primary::I(u.index)});
+                Value *rz = resize_image_if_necessary(g_.P(img), u.image_flags);
+                CompVar *bv = g_.temp(ty);
+                env.uservals[u.index] = g_.assign(bv, Rhs::V(rz));
+            } else {
+                CompVar *bv = g_.temp(ty);
+                env.uservals[u.index] = g_.assign_op(bv, getters[(int)u.kind], {Primary::I(u.index)});
+            }
+        }
+        if (needs_xy_scaling(f->flags)) gen_xy_bindings(internal_value("x", false), internal_value("y", false));
+    }
+    if (f->uses_ra) gen_ra_bindings();
+
+    gen(f->body, result, false);
+
+    env_ = env.parent;
+    size_t k = 0;
+    for (auto &v : env.vars->vars) {
+        if (k < saved.size()) v->compvar = saved[k];
+        ++k;
+    }
+    inlining_.pop_back();
+}
+
+// exprtree.c:1424-1469
+bool Lowerer::single_const(AstNode *n, int *iv) {
+    switch (n->kind) {
+        case AstNode::IntConst: *iv = n->ival; return true;
+        case AstNode::FloatConst: *iv = (int)n->fval; return true;
+        case AstNode::Tuple:
+            if (n->result.len == 1) return single_const(n->kids[0], iv);
+            return false;
+        case AstNode::Func:
+            if (n->entry->name == "__neg" && single_const(n->kids[0], iv)) { *iv = -*iv; return true; }
+            return false;
+        default: return false;
+    }
+}
+
+// Follows an image value's definitions through copies, STRIP_RESIZE and
+// RESIZE_IMAGE down to a closure or a run-time image.
+ImageChain Lowerer::resolve_image(Value *v) {
+    ImageChain c;
+    bool stripped = false;
+    for (int guard = 0; guard < 1000 && v; ++guard) {
+        Stmt *d = v->def;
+        if (!d || d->kind != Stmt::Assign) { c.base = v->index < 0 ? ImageChain::Unknown : ImageChain::Runtime; return c; }
+        const Rhs &r = d->rhs;
+        if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val) { v = r.prim.value; continue; }
+        if (r.kind == Rhs::Op && std::string(r.op->cname) == "STRIP_RESIZE" && r.args[0].kind == Primary::Val) {
+            stripped = true;
+            v = r.args[0].value;
+            continue;
+        }
+        if (r.kind == Rhs::Op && std::string(r.op->cname) == "RESIZE_IMAGE" && r.args[0].kind == Primary::Val) {
+            if (!stripped) c.factors.push_back({r.args[1], r.args[2]});
+            stripped = false;   // a strip only removes the one resize directly below it
+            v = r.args[0].value;
+            continue;
+        }
+        if (r.kind == Rhs::Closure && r.filter->kind == Filter::MathMap) {
+            c.base = ImageChain::MathMapClosure;
+            c.closure_def = d;
+            return c;
+        }
+        c.base = ImageChain::Runtime;
+        return c;
+    }
+    c.base = ImageChain::Runtime;
+    return c;
+}
+
+// EXPR_FILTER_CLOSURE, compiler.c:2165-2222
+void Lowerer::gen_closure(AstNode *n, CompVar **dest, bool alloced) {
+    Filter *callee = n->filter;
+    std::vector<Primary> prims;
+    for (size_t i = 0; i < n->kids.size(); ++i) {
+        std::vector<CompVar *> a = gen_new(n->kids[i]);
+        const UservalInfo &u = callee->uservals[i];
+        if (u.kind == UvKind::Color) {
+            CompVar *c = g_.temp(Ty::Color);
+            g_.assign_op(c, "MAKE_COLOR", {g_.P(a[0]), g_.P(a[1]), g_.P(a[2]), g_.P(a[3])});
+            prims.push_back(g_.P(c));
+        } else if (u.kind == UvKind::Image) {
+            CompVar *c = g_.temp(Ty::Image);
+            g_.assign_op(c, "STRIP_RESIZE", {g_.P(a[0])});
+            prims.push_back(g_.P(c));
+        } else
+            prims.push_back(g_.P(a[0]));
+    }
+    CompVar *image = g_.temp(Ty::Image);
+    Rhs r;
+    r.kind = Rhs::Closure;
+    r.filter = callee;
+    r.args = prims;
+    g_.assign(image, r);
+    Value *rz = resize_image_if_necessary(g_.P(image), env_->filter->flags);
+    if (!alloced) dest[0] = g_.temp(Ty::Image);
+    g_.assign(dest[0], Rhs::V(rz));
+}
+
+void Lowerer::gen_func(AstNode *n, CompVar **dest, bool alloced) {
+    std::vector<std::vector<CompVar *>> args;
+    std::vector<TInfo> types;
+    for (AstNode *k : n->kids) {
+        args.push_back(gen_new(k));
+        types.push_back(k->result);
+    }
+    std::vector<CompVar *> result(n->result.len);
+    for (int i = 0; i < n->result.len; ++i) {
+        if (!alloced) {
+            bool is_image = n->result.tag == m_.tags.image && n->result.len == 1;
+            dest[i] = g_.temp(is_image ? Ty::Image : Ty::Int);
+        }
+        result[i] = dest[i];
+    }
+    // Application of a MathMap closure: inline the callee at the sampled position.
+    if (n->entry->id == "origValXY") {
+        ImageChain chain = resolve_image(args[2][0]->current);
+        if (chain.base == ImageChain::MathMapClosure) {
+            CompVar *x = args[0][0], *y = args[0][1];
+            for (auto &fac : chain.factors) {   // compopt/resize.c:29-98
+                CompVar *nx = g_.temp(), *ny = g_.temp();
+                g_.assign_op(nx, "MUL", {g_.P(x), fac.first});
+                g_.assign_op(ny, "MUL", {g_.P(y), fac.second});
+                x = nx;
+                y = ny;
+            }
+            std::vector<Primary> cargs = chain.closure_def->rhs.args;
+            cargs.push_back(g_.P(x));
+            cargs.push_back(g_.P(y));
+            cargs.push_back(g_.P(args[1][0]));
+            CompVar *res[4];
+            gen_filter(chain.closure_def->rhs.filter, &cargs, res);
+            for (int i = 0; i < 4; ++i) g_.copy(result[i], res[i]);
+            return;
+        }
+    }
+    GenScope scope(g_);
+    n->entry->gen(g_, args, types, result);
+}
+
+void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
+    switch (n->kind) {
+        case AstNode::IntConst:
+            if (!alloced) dest[0] = g_.temp();
+            g_.assign(dest[0], Rhs::I(n->ival));
+            break;
+        case AstNode::FloatConst:
+            if (!alloced) dest[0] = g_.temp(Ty::Float);
+            g_.assign(dest[0], Rhs::F(n->fval));
+            break;
+        case AstNode::Tuple:
+            for (size_t i = 0; i < n->kids.size(); ++i) gen(n->kids[i], dest + i, alloced);
+            break;
+        case AstNode::Select: {
+            std::vector<CompVar *> temps = gen_new(n->kids[0]);
+            int len = n->kids[0]->result.len;
+            for (size_t i = 0; i < n->subs.size(); ++i) {
+                int sub;
+                if (!single_const(n->subs[i], &sub))
+                    throw CompileError("dynamic tuple subscripts (tree vectors) are not supported yet", n->pos);
+                if (sub < 0) sub = 0;
+                if (sub >= len) sub = len - 1;
+                if (!alloced) dest[i] = temps[sub];
+                else g_.copy(dest[i], temps[sub]);
+            }
+            break;
+        }
+        case AstNode::Var:
+            alloc_var(n->var);
+            for (int i = 0; i < n->var->type.len; ++i) {
+                if (!alloced) dest[i] = n->var->compvar[i];
+                else g_.copy(dest[i], n->var->compvar[i]);
+            }
+            break;
+        case AstNode::Internal: {
+            if (!alloced) dest[0] = g_.temp();
+            auto it = env_->internals.find(n->name);
+            if (it != env_->internals.end()) g_.assign(dest[0], Rhs::V(it->second));
+            else g_.assign(dest[0], Rhs::Int(n->name));
+            break;
+        }
+        case AstNode::Assign:
+            alloc_var(n->var);
+            gen(n->kids[0], n->var->compvar.data(), true);
+            for (int i = 0; i < n->result.len; ++i) {
+                if (alloced) g_.copy(dest[i], n->var->compvar[i]);
+                else dest[i] = n->var->compvar[i];
+            }
+            break;
+        case AstNode::SubAssign: {
+            alloc_var(n->var);
+            std::vector<CompVar *> temps = gen_new(n->kids[0]);
+            int len = n->var->type.len;
+            for (size_t i = 0; i < n->subs.size(); ++i) {
+                int sub;
+                if (!single_const(n->subs[i], &sub))
+                    throw CompileError("dynamic tuple subscripts (tree vectors) are not supported yet", n->pos);
+                if (sub < 0) sub = 0;
+                if (sub >= len) sub = len - 1;
+                g_.copy(n->var->compvar[sub], temps[i]);
+                if (alloced) g_.copy(dest[i], temps[i]);
+                else dest[i] = temps[i];
+            }
+            break;
+        }
+        case AstNode::Cast: gen(n->kids[0], dest, alloced); break;
+        case AstNode::Func: gen_func(n, dest, alloced); break;
+        case AstNode::Seq: {
+            gen_new(n->kids[0]);
+            gen(n->kids[1], dest, alloced);
+            break;
+        }
+        case AstNode::IfThen:
+        case AstNode::IfThenElse: {
+            bool is_image = n->result.tag == m_.tags.image && n->result.len == 1;
+            std::vector<CompVar *> result(n->result.len);
+            for (auto &r : result) r = g_.temp(is_image ? Ty::Image : Ty::Int);
+            std::vector<CompVar *> cond = gen_new(n->kids[0]);
+            g_.start_if(Rhs::V(cond[0]->current));
+            gen(n->kids[1], result.data(), true);
+            g_.switch_branch();
+            if (n->kind == AstNode::IfThenElse) gen(n->kids[2], result.data(), true);
+            g_.end_if();
+            for (int i = 0; i < n->result.len; ++i) {
+                if (alloced) g_.copy(dest[i], result[i]);
+                else dest[i] = result[i];
+            }
+            break;
+        }
+        case AstNode::While:
+        case AstNode::DoWhile: {
+            CompVar *inv = g_.temp();
+            if (n->kind == AstNode::DoWhile) gen_new(n->kids[1]);
+            gen(n->kids[0], &inv, true);
+            g_.start_while(inv);
+            gen_new(n->kids[1]);
+            gen(n->kids[0], &inv, true);
+            g_.end_while();
+            if (!alloced) dest[0] = g_.temp();
+            g_.assign(dest[0], Rhs::I(0));
+            break;
+        }
+        case AstNode::Userval: {
+            if (n->uv->kind == UvKind::Color) {
+                // colours are deconstructed into four floats (compiler.c:1824-1837, :2141-2150)
+                auto it = env_->uservals.find(n->uv->index);
+                CompVar *c = g_.temp(Ty::Color);
+                if (it != env_->uservals.end()) g_.assign(c, Rhs::V(it->second));
+                else g_.assign_op(c, "USERVAL_COLOR_ACCESS", {Primary::I(n->uv->index)});
+                static const char *parts[] = {"RED_FLOAT", "GREEN_FLOAT", "BLUE_FLOAT", "ALPHA_FLOAT"};
+                for (int i = 0; i < 4; ++i) {
+                    if (!alloced) dest[i] = g_.temp(Ty::Float);
+                    g_.assign_op(dest[i], parts[i], {g_.P(c)});
+                }
+            } else {
+                auto it = env_->uservals.find(n->uv->index);
+                if (it == env_->uservals.end()) throw CompileError("internal: unbound user value " + n->uv->name, n->pos);
+                if (!alloced) dest[0] = g_.temp(it->second->var->type);
+                g_.assign(dest[0], Rhs::V(it->second));
+            }
+            break;
+        }
+        case AstNode::Closure: gen_closure(n, dest, alloced); break;
+    }
+}
+
+void Lowerer::run(Filter *f) {
+    CompVar *res[4];
+    gen_filter(f, nullptr, res);
+    for (int i = 0; i < 4; ++i) code_.result[i] = res[i]->current;
+}
+
+}  // namespace
+
+std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f) {
+    if (f->kind != Filter::MathMap) throw CompileError("cannot lower a native filter");
+    std::unique_ptr<FilterCode> code(new FilterCode());
+    code->filter = f;
+    Lowerer l(m, *code);
+    l.run(f);
+    propagate_types(*code);
+    return code;
+}
+
+}  // namespace mm

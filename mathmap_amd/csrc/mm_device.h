@@ -1,0 +1,453 @@
+// Device-side runtime of JIT-compiled MathMap pixel kernels (gfx950).
+//
+// This file is prepended verbatim to every kernel string handed to hiprtc
+// (hipgen.cpp).  It restates, as __device__ code, the semantics of the reference's
+// op macros (opmacros.h:30-218), colour helpers (color.h:36-54) and pixel fetch
+// runtime (builtins/builtins.c:40-265).  Arithmetic rules that must hold for
+// parity with the cc backend:
+//   * the generated code is compiled with -ffp-contract=off (gcc for baseline
+//     x86-64 never fuses a*b+c);
+//   * real libm ops are the *double* functions applied to the promoted operand
+//     (C has no overloads: sin(float) calls sin(double)), rounded once on
+//     assignment -- hence the mm_* wrappers taking double;
+//   * float literals are printed as double literals of the float value, so C's
+//     usual arithmetic conversions decide float-vs-double exactly as in gcc.
+//
+// Compile-time switches provided by the generator (#define before this text):
+//   MM_INTERSAMPLE   1 = bilinear fetch (get_orig_val_intersample_pixel), 0 = nearest
+//   MM_SUPERSAMPLING 1 = no +0.5 in the nearest fetch (builtins.c:154-158)
+//   MM_EDGE_X / MM_EDGE_Y   edge behaviour: 0 colour, 1 wrap, 2 reflect, 3 rotate
+#ifndef MM_DEVICE_H
+#define MM_DEVICE_H
+
+#ifndef MM_INTERSAMPLE
+#define MM_INTERSAMPLE 0
+#endif
+#ifndef MM_SUPERSAMPLING
+#define MM_SUPERSAMPLING 0
+#endif
+#ifndef MM_EDGE_X
+#define MM_EDGE_X 0
+#endif
+#ifndef MM_EDGE_Y
+#define MM_EDGE_Y 0
+#endif
+
+#define MM_DEV static __device__ __forceinline__
+
+typedef unsigned int color_t;
+
+struct mm_complex { float re, im; };
+template <int N> struct mm_tup { float v[N]; };
+
+// An image *value* inside a kernel: index into the image table plus the resize
+// factors of an IMAGE_RESIZE wrapper (drawable.c:211-228).
+struct mm_image { int idx; int pw; int ph; float xf; float yf; int resized; };
+
+enum { MM_IMG_DRAWABLE = 0, MM_IMG_FLOATMAP = 1, MM_IMG_NULL = 2 };
+
+// One entry of the image table in HBM (input drawables and float maps).
+struct mm_image_desc {
+    const void *data;      // drawable: color_t[h][w] (0xRRGGBBAA); floatmap: float[h][w][4]
+    int w, h;
+    int kind;
+    int num_frames;
+    float scale_x, scale_y, middle_x, middle_y;   // userval.c:262-280
+    float ax, bx, ay, by;                          // floatmap.c:30-46
+};
+
+union mm_userval { int i; float f; color_t c; int image; };
+
+// Everything a kernel needs about the invocation / frame / slice
+// (mathmap.h:162-226).  Passed by value => lives in SGPRs.
+struct mm_args {
+    int img_width, img_height;        // __canvasPixelW/H
+    int render_width, render_height;  // __renderPixelW/H
+    int frame_render_width, frame_render_height;
+    float t;
+    int frame;
+    float R;
+    int region_x, region_y, region_width, region_height;
+    float sampling_offset_x, sampling_offset_y;
+    int first_row, num_rows;          // rows of the slice rendered by this launch
+    int output_bpp;
+    int row_stride;                   // bytes (u8 output) between output rows
+    int floatmap;                     // 1: write float4 instead of bytes
+    color_t edge_color_x, edge_color_y;
+    const mm_userval *uservals;
+    const mm_image_desc *images;
+    const void *curves;               // float[n][1024]
+    const void *gradients;            // color_t[n][1024]
+    void *out;
+    int native_slot_base;             // image-table index of native-filter result 0
+    int pad0;
+};
+
+// ---- op macros (opmacros.h:30-47) --------------------------------------------------
+#define NOP() (0.0)
+#define INT2FLOAT(x) ((float)(x))
+#define FLOAT2INT(x) ((int)(x))
+#define ADD(a, b) ((a) + (b))
+#define SUB(a, b) ((a) - (b))
+#define NEG(a) (-(a))
+#define MUL(a, b) ((a) * (b))
+#define DIV(a, b) ((float)(a) / (float)(b))
+#define MOD(a, b) (mm_fmod((a), (b)))
+#define EQ(a, b) ((a) == (b))
+#define LESS(a, b) ((a) < (b))
+#define LEQ(a, b) ((a) <= (b))
+#define NOT(a) (!(a))
+#define MIN(a, b) (((a) < (b)) ? (a) : (b))
+#define MAX(a, b) (((a) < (b)) ? (b) : (a))
+#define CLAMP01(x) (MAX(0, MIN(1, (x))))
+
+// double libm, applied to promoted operands
+MM_DEV double mm_fmod(double a, double b) { return fmod(a, b); }
+MM_DEV double mm_fabs(double a) { return fabs(a); }
+MM_DEV double mm_sqrt(double a) { return sqrt(a); }
+MM_DEV double mm_hypot(double a, double b) { return hypot(a, b); }
+MM_DEV double mm_sin(double a) { return sin(a); }
+MM_DEV double mm_cos(double a) { return cos(a); }
+MM_DEV double mm_tan(double a) { return tan(a); }
+MM_DEV double mm_asin(double a) { return asin(a); }
+MM_DEV double mm_acos(double a) { return acos(a); }
+MM_DEV double mm_atan(double a) { return atan(a); }
+MM_DEV double mm_atan2(double a, double b) { return atan2(a, b); }
+MM_DEV double mm_pow(double a, double b) { return pow(a, b); }
+MM_DEV double mm_exp(double a) { return exp(a); }
+MM_DEV double mm_log(double a) { return log(a); }
+MM_DEV double mm_sinh(double a) { return sinh(a); }
+MM_DEV double mm_cosh(double a) { return cosh(a); }
+MM_DEV double mm_tanh(double a) { return tanh(a); }
+MM_DEV double mm_asinh(double a) { return asinh(a); }
+MM_DEV double mm_acosh(double a) { return acosh(a); }
+MM_DEV double mm_atanh(double a) { return atanh(a); }
+MM_DEV double mm_floor(double a) { return floor(a); }
+MM_DEV double mm_ceil(double a) { return ceil(a); }
+MM_DEV double mm_gamma(double a) { return (a > 171.0) ? 0.0 : tgamma(a); }   // opmacros.h:43
+MM_DEV double mm_beta(double a, double b) { return exp(lgamma(a) + lgamma(b) - lgamma(a + b)); }
+
+// (float)sqrt((double)x) == correctly rounded sqrtf(x) for every float x (53 >= 2*24+2
+// bits: double rounding is innocuous for sqrt), so float operands may take the f32 path.
+MM_DEV float mm_sqrt_f32(float a) { return __fsqrt_rn(a); }
+
+// ---- complex (float _Complex) -----------------------------------------------------------
+// In the generated C, complex values only flow COMPLEX() -> c*f() -> crealf/cimagf
+// (builtins.lisp:679-941).  The functions below compute in double and round once;
+// glibc's float versions are within 1 ulp of the same values.
+MM_DEV mm_complex mm_cmake(float r, float i) { mm_complex c; c.re = r; c.im = i; return c; }
+#define COMPLEX(r, i) mm_cmake((float)(r), (float)(i))
+MM_DEV float crealf(mm_complex c) { return c.re; }
+MM_DEV float cimagf(mm_complex c) { return c.im; }
+
+struct mm_dc { double re, im; };
+MM_DEV mm_dc mm_dcmake(double r, double i) { mm_dc c; c.re = r; c.im = i; return c; }
+MM_DEV mm_dc mm_widen(mm_complex c) { return mm_dcmake((double)c.re, (double)c.im); }
+MM_DEV mm_complex mm_narrow(mm_dc c) { return mm_cmake((float)c.re, (float)c.im); }
+MM_DEV mm_dc mm_dcmul(mm_dc a, mm_dc b) { return mm_dcmake(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+MM_DEV mm_dc mm_dcadd(mm_dc a, mm_dc b) { return mm_dcmake(a.re + b.re, a.im + b.im); }
+MM_DEV mm_dc mm_dcsub(mm_dc a, mm_dc b) { return mm_dcmake(a.re - b.re, a.im - b.im); }
+MM_DEV mm_dc mm_dcdiv(mm_dc a, mm_dc b) {
+    double d = b.re * b.re + b.im * b.im;
+    return mm_dcmake((a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d);
+}
+MM_DEV mm_dc mm_dclog(mm_dc z) { return mm_dcmake(log(hypot(z.re, z.im)), atan2(z.im, z.re)); }
+MM_DEV mm_dc mm_dcexp(mm_dc z) {
+    double e = exp(z.re), s, c;
+    sincos(z.im, &s, &c);
+    if (z.im == 0.0) return mm_dcmake(e, z.im);
+    return mm_dcmake(e * c, e * s);
+}
+MM_DEV mm_dc mm_dcsqrt(mm_dc z) {
+    if (z.re == 0.0 && z.im == 0.0) return mm_dcmake(0.0, z.im);
+    double r = hypot(z.re, z.im);
+    if (z.re > 0.0) {
+        double t = sqrt(0.5 * (r + z.re));
+        return mm_dcmake(t, z.im / (2.0 * t));
+    }
+    double t = sqrt(0.5 * (r - z.re));
+    return mm_dcmake(fabs(z.im) / (2.0 * t), copysign(t, z.im));
+}
+
+MM_DEV mm_complex csqrtf(mm_complex z) { return mm_narrow(mm_dcsqrt(mm_widen(z))); }
+MM_DEV mm_complex cexpf(mm_complex z) { return mm_narrow(mm_dcexp(mm_widen(z))); }
+MM_DEV mm_complex clogf(mm_complex z) { return mm_narrow(mm_dclog(mm_widen(z))); }
+MM_DEV float cargf(mm_complex z) { return (float)atan2((double)z.im, (double)z.re); }
+// glibc: cpowf(x, c) = cexpf(c * clogf(x)) with every step rounded to float
+MM_DEV mm_complex cpowf(mm_complex x, mm_complex c) {
+    mm_complex l = clogf(x);
+    mm_complex p = mm_cmake(c.re * l.re - c.im * l.im, c.re * l.im + c.im * l.re);
+    return cexpf(p);
+}
+MM_DEV mm_complex csinf(mm_complex z) {
+    double s, c;
+    sincos((double)z.re, &s, &c);
+    return mm_cmake((float)(s * cosh((double)z.im)), (float)(c * sinh((double)z.im)));
+}
+MM_DEV mm_complex ccosf(mm_complex z) {
+    double s, c;
+    sincos((double)z.re, &s, &c);
+    return mm_cmake((float)(c * cosh((double)z.im)), (float)(-s * sinh((double)z.im)));
+}
+MM_DEV mm_complex ctanf(mm_complex z) {
+    double s2, c2;
+    sincos(2.0 * (double)z.re, &s2, &c2);
+    double y2 = 2.0 * (double)z.im;
+    if (fabs(y2) > 700.0) return mm_cmake((float)(4.0 * s2 * exp(-2.0 * fabs(y2)) ), (float)copysign(1.0, y2));
+    double d = c2 + cosh(y2);
+    return mm_cmake((float)(s2 / d), (float)(sinh(y2) / d));
+}
+MM_DEV mm_complex csinhf(mm_complex z) {
+    double s, c;
+    sincos((double)z.im, &s, &c);
+    return mm_cmake((float)(sinh((double)z.re) * c), (float)(cosh((double)z.re) * s));
+}
+MM_DEV mm_complex ccoshf(mm_complex z) {
+    double s, c;
+    sincos((double)z.im, &s, &c);
+    return mm_cmake((float)(cosh((double)z.re) * c), (float)(sinh((double)z.re) * s));
+}
+MM_DEV mm_complex ctanhf(mm_complex z) {
+    double s2, c2;
+    sincos(2.0 * (double)z.im, &s2, &c2);
+    double x2 = 2.0 * (double)z.re;
+    if (fabs(x2) > 700.0) return mm_cmake((float)copysign(1.0, x2), (float)(4.0 * s2 * exp(-2.0 * fabs(x2))));
+    double d = cosh(x2) + c2;
+    return mm_cmake((float)(sinh(x2) / d), (float)(s2 / d));
+}
+MM_DEV mm_dc mm_dcasinh(mm_dc z) {
+    mm_dc one = mm_dcmake(1.0, 0.0);
+    // fold into the right half plane for accuracy, asinh is odd
+    bool neg = z.re < 0.0 || (z.re == 0.0 && signbit(z.re));
+    mm_dc w = neg ? mm_dcmake(-z.re, -z.im) : z;
+    mm_dc r = mm_dclog(mm_dcadd(w, mm_dcsqrt(mm_dcadd(mm_dcmul(w, w), one))));
+    return neg ? mm_dcmake(-r.re, -r.im) : r;
+}
+MM_DEV mm_complex casinhf(mm_complex z) { return mm_narrow(mm_dcasinh(mm_widen(z))); }
+MM_DEV mm_complex casinf(mm_complex z) {   // casin(z) = -i casinh(i z)
+    mm_dc r = mm_dcasinh(mm_dcmake(-(double)z.im, (double)z.re));
+    return mm_cmake((float)r.im, (float)-r.re);
+}
+MM_DEV mm_complex cacosf(mm_complex z) {   // pi/2 - casin(z)
+    mm_dc r = mm_dcasinh(mm_dcmake(-(double)z.im, (double)z.re));
+    return mm_cmake((float)(1.5707963267948966 - r.im), (float)r.re);
+}
+MM_DEV mm_dc mm_dcatanh(mm_dc z) {   // 1/2 (log(1+z) - log(1-z))
+    mm_dc one = mm_dcmake(1.0, 0.0);
+    mm_dc a = mm_dclog(mm_dcadd(one, z)), b = mm_dclog(mm_dcsub(one, z));
+    return mm_dcmake(0.5 * (a.re - b.re), 0.5 * (a.im - b.im));
+}
+MM_DEV mm_complex catanhf(mm_complex z) { return mm_narrow(mm_dcatanh(mm_widen(z))); }
+MM_DEV mm_complex catanf(mm_complex z) {   // catan(z) = -i catanh(i z)
+    mm_dc r = mm_dcatanh(mm_dcmake(-(double)z.im, (double)z.re));
+    return mm_cmake((float)r.im, (float)-r.re);
+}
+MM_DEV mm_complex cacoshf(mm_complex z) {  // log(z + sqrt(z+1) sqrt(z-1))
+    mm_dc w = mm_widen(z), one = mm_dcmake(1.0, 0.0);
+    mm_dc r = mm_dclog(mm_dcadd(w, mm_dcmul(mm_dcsqrt(mm_dcadd(w, one)), mm_dcsqrt(mm_dcsub(w, one)))));
+    return mm_narrow(r);
+}
+// builtins/spec_func.c:35-64 (Luke's approximation; double-complex internally)
+MM_DEV mm_dc mm_dcpow(mm_dc a, mm_dc b) { return mm_dcexp(mm_dcmul(b, mm_dclog(a))); }
+MM_DEV mm_complex cgamma(mm_complex zf) {
+    const double coeff[7] = {41.624436916439068, -51.224241022374774, 11.338755813488977, -0.747732687772388,
+                             0.008782877493061, -1.899030264e-6, 1.946335e-9};
+    mm_dc z = mm_widen(zf);
+    mm_dc denom = mm_dcmake(1.0, 0.0);
+    int guard = 0;
+    // the reference recurses on float-rounded arguments; unrolled here as a loop
+    while (z.re < 0.0 && guard++ < 64) {
+        int flr = (int)-floor(z.re);
+        mm_dc d = mm_dcmake(1.0, 0.0);
+        for (int n = 0; n < flr; ++n) d = mm_dcmul(d, mm_dcmake(z.re + n, z.im));
+        denom = mm_dcmul(denom, d);
+        mm_complex zn = mm_cmake((float)(z.re + flr), (float)z.im);   // argument passes through float
+        z = mm_widen(zn);
+    }
+    mm_dc w = mm_dcmake(z.re - 1.0, z.im);
+    mm_dc s = mm_dcmake(coeff[0], 0.0), H = mm_dcmake(1.0, 0.0);
+    for (int n = 1; n < 7; ++n) {
+        H = mm_dcmul(H, mm_dcdiv(mm_dcmake(w.re + 1 - n, w.im), mm_dcmake(w.re + n, w.im)));
+        s = mm_dcadd(s, mm_dcmake(coeff[n] * H.re, coeff[n] * H.im));
+    }
+    mm_dc e = mm_dcexp(mm_dcmake(-w.re - 5.5, -w.im));
+    mm_dc p = mm_dcpow(mm_dcmake(w.re + 5.5, w.im), mm_dcmake(w.re + 0.5, w.im));
+    mm_dc r = mm_dcmul(mm_dcmul(mm_dcmake(2.506628274631 * e.re, 2.506628274631 * e.im), p), s);
+    return mm_narrow(mm_dcdiv(r, denom));
+}
+
+// ---- colours (new_template.c.in:71-77, opmacros.h:147-154,176-181) --------------------------
+#define MAKE_RGBA_COLOR(r, g, b, a) \
+    ((((color_t)(r)) << 24) | (((color_t)(g)) << 16) | (((color_t)(b)) << 8) | ((color_t)(a)))
+#define RED(c) ((c) >> 24)
+#define GREEN(c) (((c) >> 16) & 0xff)
+#define BLUE(c) (((c) >> 8) & 0xff)
+#define ALPHA(c) ((c)&0xff)
+#define RED_FLOAT(c) (RED(c) / 255.0)
+#define GREEN_FLOAT(c) (GREEN(c) / 255.0)
+#define BLUE_FLOAT(c) (BLUE(c) / 255.0)
+#define ALPHA_FLOAT(c) (ALPHA(c) / 255.0)
+#define MAKE_COLOR(r, g, b, a) \
+    (MAKE_RGBA_COLOR(CLAMP01((r)) * 255, CLAMP01((g)) * 255, CLAMP01((b)) * 255, CLAMP01((a)) * 255))
+#define TUPLE_NTH(t, n) ((t).v[(n)])
+
+MM_DEV mm_tup<4> mm_tuple_from_color(color_t c) {
+    mm_tup<4> t;
+    t.v[0] = RED_FLOAT(c);
+    t.v[1] = GREEN_FLOAT(c);
+    t.v[2] = BLUE_FLOAT(c);
+    t.v[3] = ALPHA_FLOAT(c);
+    return t;
+}
+
+// ---- user values / images ----------------------------------------------------------------------
+#define USERVAL_INT_ACCESS(n) (A.uservals[(n)].i)
+#define USERVAL_FLOAT_ACCESS(n) (A.uservals[(n)].f)
+#define USERVAL_BOOL_ACCESS(n) (A.uservals[(n)].i)
+#define USERVAL_COLOR_ACCESS(n) (A.uservals[(n)].c)
+#define USERVAL_CURVE_ACCESS(n) (A.uservals[(n)].i)
+#define USERVAL_GRADIENT_ACCESS(n) (A.uservals[(n)].i)
+#define USERVAL_IMAGE_ACCESS(n) (mm_image_from_table(A, A.uservals[(n)].image))
+
+MM_DEV mm_image mm_image_from_table(const mm_args &A, int idx) {
+    mm_image im;
+    im.idx = idx;
+    im.pw = A.images[idx].w;
+    im.ph = A.images[idx].h;
+    im.xf = 1.0f;
+    im.yf = 1.0f;
+    im.resized = 0;
+    return im;
+}
+MM_DEV mm_image mm_null_image() { mm_image im; im.idx = -1; im.pw = 0; im.ph = 0; im.xf = im.yf = 1.0f; im.resized = 0; return im; }
+#define UNINITED_IMAGE (mm_null_image())
+#define IMAGE_PIXEL_WIDTH(i) ((i).pw)
+#define IMAGE_PIXEL_HEIGHT(i) ((i).ph)
+MM_DEV mm_image mm_resize_image(mm_image i, float xf, float yf) { i.xf = xf; i.yf = yf; i.resized = 1; return i; }
+MM_DEV mm_image mm_strip_resize(mm_image i) { i.xf = 1.0f; i.yf = 1.0f; i.resized = 0; return i; }
+#define RESIZE_IMAGE(i, xf, yf) (mm_resize_image((i), (xf), (yf)))
+#define STRIP_RESIZE(i) (mm_strip_resize((i)))
+
+#define USER_CURVE_POINTS 1024
+#define APPLY_CURVE(c, p) (((const float *)A.curves)[(c)*USER_CURVE_POINTS + (int)(CLAMP01((p)) * (USER_CURVE_POINTS - 1))])
+#define APPLY_GRADIENT(g, p) \
+    (mm_tuple_from_color(((const color_t *)A.gradients)[(g)*USER_CURVE_POINTS + (int)(CLAMP01((p)) * (USER_CURVE_POINTS - 1))]))
+
+// ---- pixel fetch (builtins.c:40-265, mathmap.c:1195-1209, mathmap_cmdline.c:131-184) -------------
+MM_DEV void mm_apply_edge_behaviour(int &x, int &y, int width, int height) {
+#if MM_EDGE_X == 1
+    if (x < 0) x = x % width + width;
+    else if (x >= width) x %= width;
+#elif MM_EDGE_X == 2
+    if (x < 0) x = -x % width;
+    else if (x >= width) x = (width - 1) - (x % width);
+#elif MM_EDGE_X == 3
+    if (x < 0) { x = -x % width; y = (height - 1) - y; }
+    else if (x >= width) { x = (width - 1) - (x % width); y = (height - 1) - y; }
+#endif
+#if MM_EDGE_Y == 1
+    if (y < 0) y = y % height + height;
+    else if (y >= height) y %= height;
+#elif MM_EDGE_Y == 2
+    if (y < 0) y = -y % height;
+    else if (y >= height) y = (height - 1) - (y % height);
+#elif MM_EDGE_Y == 3
+    if (y < 0) { x = (width - 1) - x; y = -y % height; }
+    else if (y >= height) { x = (width - 1) - x; y = (height - 1) - (y % height); }
+#endif
+}
+
+MM_DEV color_t mm_get_pixel(const mm_args &A, const mm_image_desc &d, int x, int y, int frame) {
+    if (d.kind == MM_IMG_NULL) return MAKE_RGBA_COLOR(255, 255, 255, 255);
+    mm_apply_edge_behaviour(x, y, d.w, d.h);
+    if (x < 0 || x >= d.w) return A.edge_color_x;
+    if (y < 0 || y >= d.h) return A.edge_color_y;
+    if (frame < 0 || frame >= d.num_frames) return MAKE_RGBA_COLOR(255, 255, 255, 255);
+    return ((const color_t *)d.data)[(long)y * d.w + x];
+}
+
+MM_DEV color_t mm_orig_val_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
+    x = (x + d.middle_x) * d.scale_x;
+    y = -((y - d.middle_y) * d.scale_y);
+#if !MM_SUPERSAMPLING
+    x += 0.5;   // double add, rounded back to float
+    y += 0.5;
+#endif
+    return mm_get_pixel(A, d, (int)floor((double)x), (int)floor((double)y), frame);
+}
+
+MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
+    x = (x + d.middle_x) * d.scale_x;
+    y = -((y - d.middle_y) * d.scale_y);
+    int x1 = (int)floor((double)x), x2 = x1 + 1;
+    int y1 = (int)floor((double)y), y2 = y1 + 1;
+    float x2fact = x - x1, y2fact = y - y1;
+    float x1fact = 1.0 - x2fact, y1fact = 1.0 - y2fact;
+    float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
+    color_t p1 = mm_get_pixel(A, d, x1, y1, frame), p2 = mm_get_pixel(A, d, x1, y2, frame);
+    color_t p3 = mm_get_pixel(A, d, x2, y1, frame), p4 = mm_get_pixel(A, d, x2, y2, frame);
+    float r = RED(p1) * p1fact, g = GREEN(p1) * p1fact, b = BLUE(p1) * p1fact, a = ALPHA(p1) * p1fact;
+    r = r + RED(p2) * p2fact; g = g + GREEN(p2) * p2fact; b = b + BLUE(p2) * p2fact; a = a + ALPHA(p2) * p2fact;
+    r = r + RED(p3) * p3fact; g = g + GREEN(p3) * p3fact; b = b + BLUE(p3) * p3fact; a = a + ALPHA(p3) * p3fact;
+    r = r + RED(p4) * p4fact; g = g + GREEN(p4) * p4fact; b = b + BLUE(p4) * p4fact; a = a + ALPHA(p4) * p4fact;
+    return MAKE_RGBA_COLOR((color_t)rintf(r) & 0xff, (color_t)rintf(g) & 0xff, (color_t)rintf(b) & 0xff,
+                           (color_t)rintf(a) & 0xff);
+}
+
+MM_DEV mm_tup<4> mm_floatmap_pixel(const mm_image_desc &d, float x, float y) {
+    mm_tup<4> t;
+    int ix = (int)lrintf(d.ax * x + d.bx);
+    int iy = (int)lrintf(d.ay * y + d.by);
+    if (ix < 0 || ix >= d.w || iy < 0 || iy >= d.h) {
+        t.v[0] = t.v[1] = t.v[2] = t.v[3] = 0.0f;
+        return t;
+    }
+    const float4 p = ((const float4 *)d.data)[(long)iy * d.w + ix];
+    t.v[0] = p.x; t.v[1] = p.y; t.v[2] = p.z; t.v[3] = p.w;
+    return t;
+}
+
+// opmacros.h:199-216 (closure images are applied at compile time and never reach here)
+MM_DEV mm_tup<4> mm_orig_val(const mm_args &A, float x, float y, mm_image img, float f) {
+    if (img.resized) { x *= img.xf; y *= img.yf; }
+    if (img.idx < 0) { mm_tup<4> t; t.v[0] = t.v[1] = t.v[2] = t.v[3] = 1.0f; return t; }
+    const mm_image_desc &d = A.images[img.idx];
+    if (d.kind == MM_IMG_FLOATMAP) return mm_floatmap_pixel(d, x, y);
+#if MM_INTERSAMPLE
+    return mm_tuple_from_color(mm_orig_val_intersample_pixel(A, d, x, y, (int)f));
+#else
+    return mm_tuple_from_color(mm_orig_val_pixel(A, d, x, y, (int)f));
+#endif
+}
+#define ORIG_VAL(x, y, i, f) (mm_orig_val(A, (x), (y), (i), (f)))
+
+// ---- coordinates and output (opmacros.h:156-157, new_template.c.in:243-309) ---------------------
+#define CALC_VIRTUAL_X(pxl, size, off) (((pxl) - ((size)-1) / 2.0 + (off)) / (((size)-1) / 2.0))
+#define CALC_VIRTUAL_Y(pxl, size, off) ((-(pxl) + ((size)-1) / 2.0 - (off)) / (((size)-1) / 2.0))
+
+MM_DEV void mm_store_pixel(const mm_args &A, int row_in_launch, int col, const mm_tup<4> &rt) {
+    if (A.floatmap) {
+        float4 *o = (float4 *)A.out + (long)row_in_launch * A.frame_render_width + col;
+        *o = make_float4(rt.v[0], rt.v[1], rt.v[2], rt.v[3]);
+        return;
+    }
+    unsigned char *p = (unsigned char *)A.out + (long)row_in_launch * A.row_stride + (long)col * A.output_bpp;
+    const int bpp = A.output_bpp;
+    if (bpp == 4) {
+        // one aligned 32-bit store: bytes R,G,B,A in memory order
+        unsigned r = (unsigned char)(CLAMP01(rt.v[0]) * 255.0), g = (unsigned char)(CLAMP01(rt.v[1]) * 255.0);
+        unsigned b = (unsigned char)(CLAMP01(rt.v[2]) * 255.0), a = (unsigned char)(CLAMP01(rt.v[3]) * 255.0);
+        *(unsigned *)p = r | (g << 8) | (b << 16) | (a << 24);
+        return;
+    }
+    if (bpp == 1 || bpp == 2)
+        p[0] = (CLAMP01(rt.v[0]) * 0.299 + CLAMP01(rt.v[1]) * 0.587 + CLAMP01(rt.v[2]) * 0.114) * 255.0;
+    else {
+        p[0] = CLAMP01(rt.v[0]) * 255.0;
+        p[1] = CLAMP01(rt.v[1]) * 255.0;
+        p[2] = CLAMP01(rt.v[2]) * 255.0;
+    }
+    if (bpp == 2 || bpp == 4) p[bpp - 1] = CLAMP01(rt.v[3]) * 255.0;
+}
+
+#endif  // MM_DEVICE_H

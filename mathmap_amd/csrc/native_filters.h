@@ -1,0 +1,28 @@
+// Native filters (the reference's native-filters/*.c) as hand-written HIP kernels.
+// Called by the runtime between the prologue and the pixel kernel; inputs and
+// outputs stay in HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "mm_host_abi.h"
+
+namespace mm {
+
+// Scratch buffers reused across calls (sized for the largest map seen).
+struct NativeWorkspace {
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *reserve(size_t bytes);
+    void release();
+};
+
+// Runs native filter `func` with the arguments recorded by the prologue kernel.
+// `out_map` is a float[h][w][4] device buffer.  Returns 0 on success.
+int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
+                      int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
+                      std::string *err);
+
+}  // namespace mm

@@ -1,0 +1,282 @@
+// Clean-up and analysis passes over the structured SSA IR.
+//
+//  * copy propagation between compvars of equal type, dead-code elimination
+//    (the reference runs the same two among its passes, compiler.c:4702-4764;
+//    they never change a computed value, only shrink the kernel text)
+//  * constness analysis + slicing into a frame-constant prologue and the per-pixel
+//    body (reference: analyze_constants compiler.c:3208-3234, slices
+//    compiler.c:4550-4642).  On the GPU only one split matters: values that do not
+//    depend on the pixel position are computed once per frame by a one-lane
+//    prologue kernel and reach the pixel kernel through a small constant buffer
+//    (scalar loads), everything else runs per work-item.
+#include <cstring>
+#include <functional>
+#include <map>
+#include <set>
+
+#include "passes.h"
+
+namespace mm {
+
+namespace {
+
+void for_each_prim(Rhs &r, const std::function<void(Primary &)> &fn) {
+    if (r.kind == Rhs::Prim) fn(r.prim);
+    for (Primary &p : r.args) fn(p);
+}
+
+void for_each_stmt(Block &b, const std::function<void(Stmt *)> &fn) {
+    for (Stmt *s : b) {
+        fn(s);
+        if (s->kind == Stmt::If) {
+            for_each_stmt(s->then_, fn);
+            for_each_stmt(s->else_, fn);
+            for_each_stmt(s->phis, fn);
+        } else if (s->kind == Stmt::While) {
+            for_each_stmt(s->phis, fn);
+            for_each_stmt(s->body, fn);
+        }
+    }
+}
+
+bool rhs_pure(const Rhs &r) {
+    if (r.kind == Rhs::Op) return r.op->pure;
+    return true;   // native closures are memoised per frame -> treated as pure (mathmap_common.c:321-377 is_pure)
+}
+
+}  // namespace
+
+// v = w (same compvar type)  ==>  uses of v read w
+bool copy_propagate(FilterCode &code) {
+    std::map<Value *, Primary> repl;
+    for_each_stmt(code.body, [&](Stmt *s) {
+        if (s->kind != Stmt::Assign || s->rhs.kind != Rhs::Prim) return;
+        const Primary &p = s->rhs.prim;
+        if (p.kind == Primary::Val) {
+            if (p.value->index < 0) return;
+            if (p.value->var->type != s->lhs->var->type) return;
+            if (p.value->var->type == Ty::Tuple && p.value->var->tuple_len != s->lhs->var->tuple_len) return;
+            repl[s->lhs] = p;
+        } else if ((p.kind == Primary::IntConst && s->lhs->var->type == Ty::Int) ||
+                   (p.kind == Primary::FloatConst && s->lhs->var->type == Ty::Float)) {
+            // a constant of exactly the variable's type can stand in for it: the C
+            // expression sees the same operand type either way (floats print as the
+            // double literal of the float value, cc.c / ops.lisp:343-358)
+            repl[s->lhs] = p;
+        }
+    });
+    if (repl.empty()) return false;
+    auto resolve = [&](Primary p) {
+        for (int guard = 0; guard < 10000 && p.kind == Primary::Val; ++guard) {
+            auto it = repl.find(p.value);
+            if (it == repl.end()) break;
+            p = it->second;
+        }
+        return p;
+    };
+    bool changed = false;
+    auto fix = [&](Primary &p) {
+        if (p.kind != Primary::Val) return;
+        Primary q = resolve(p);
+        if (q.kind != p.kind || q.value != p.value) { p = q; changed = true; }
+    };
+    for_each_stmt(code.body, [&](Stmt *s) {
+        switch (s->kind) {
+            case Stmt::Assign: for_each_prim(s->rhs, fix); break;
+            case Stmt::Phi: for_each_prim(s->rhs, fix); for_each_prim(s->rhs2, fix); break;
+            case Stmt::If:
+            case Stmt::While: for_each_prim(s->cond, fix); break;
+            default: break;
+        }
+    });
+    for (int i = 0; i < 4; ++i)
+        if (code.result[i]) {
+            Primary p = resolve(Primary::V(code.result[i]));
+            // results must stay values; only follow value->value copies
+            if (p.kind == Primary::Val) code.result[i] = p.value;
+        }
+    return changed;
+}
+
+bool eliminate_dead_code(FilterCode &code) {
+    bool any = false;
+    for (;;) {
+        std::map<Value *, int> uses;
+        auto count = [&](Primary &p) { if (p.kind == Primary::Val) ++uses[p.value]; };
+        for_each_stmt(code.body, [&](Stmt *s) {
+            switch (s->kind) {
+                case Stmt::Assign: for_each_prim(s->rhs, count); break;
+                case Stmt::Phi: {
+                    // a loop phi feeding only itself is dead: do not count self-uses
+                    auto cnt = [&](Primary &p) { if (p.kind == Primary::Val && p.value != s->lhs) ++uses[p.value]; };
+                    for_each_prim(s->rhs, cnt);
+                    for_each_prim(s->rhs2, cnt);
+                    break;
+                }
+                case Stmt::If:
+                case Stmt::While: for_each_prim(s->cond, count); break;
+                default: break;
+            }
+        });
+        for (int i = 0; i < 4; ++i)
+            if (code.result[i]) ++uses[code.result[i]];
+        bool changed = false;
+        std::function<void(Block &)> sweep = [&](Block &b) {
+            Block out;
+            for (Stmt *s : b) {
+                bool dead = false;
+                if (s->kind == Stmt::Assign && uses[s->lhs] == 0 && rhs_pure(s->rhs)) dead = true;
+                if (s->kind == Stmt::Phi && uses[s->lhs] == 0) dead = true;
+                if (s->kind == Stmt::If) {
+                    sweep(s->then_);
+                    sweep(s->else_);
+                    sweep(s->phis);
+                    if (s->then_.empty() && s->else_.empty() && s->phis.empty()) dead = true;
+                }
+                if (s->kind == Stmt::While) {
+                    sweep(s->phis);
+                    sweep(s->body);
+                }
+                if (s->kind == Stmt::Nil) dead = true;
+                if (dead) changed = true;
+                else out.push_back(s);
+            }
+            b.swap(out);
+        };
+        sweep(code.body);
+        if (!changed) break;
+        any = true;
+    }
+    return any;
+}
+
+void optimize(FilterCode &code) {
+    propagate_types(code);
+    for (int i = 0; i < 20; ++i) {
+        bool c = copy_propagate(code);
+        c |= eliminate_dead_code(code);
+        if (!c) break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Frame-constant analysis
+// ---------------------------------------------------------------------------
+namespace {
+
+bool internal_is_frame_const(const std::string &n) { return n != "x" && n != "y"; }
+
+}  // namespace
+
+// Marks every value that depends on the pixel position (directly, through data
+// flow, or through control flow) as not hoistable; the rest is `hoisted`.  Then
+// statements are assigned to the prologue slice, the pixel slice, or both
+// (control statements whose bodies contain work of both kinds).
+void analyze_frame_constants(FilterCode &code) {
+    for (Value &v : code.values) v.hoisted = true;
+    bool changed = true;
+    auto prim_hoisted = [](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted; };
+    auto rhs_hoisted = [&](const Rhs &r) {
+        if (r.kind == Rhs::Internal) return internal_is_frame_const(r.internal);
+        if (r.kind == Rhs::Op && !r.op->pure) return false;
+        if (r.kind == Rhs::Prim) return prim_hoisted(r.prim);
+        for (const Primary &p : r.args)
+            if (!prim_hoisted(p)) return false;
+        return true;
+    };
+    std::function<void(Block &, bool)> walk = [&](Block &b, bool ctx) {
+        for (Stmt *s : b) {
+            switch (s->kind) {
+                case Stmt::Assign: {
+                    bool h = ctx && rhs_hoisted(s->rhs);
+                    if (!h && s->lhs->hoisted) { s->lhs->hoisted = false; changed = true; }
+                    break;
+                }
+                case Stmt::If: {
+                    bool c = ctx && rhs_hoisted(s->cond);
+                    walk(s->then_, c);
+                    walk(s->else_, c);
+                    for (Stmt *p : s->phis) {
+                        bool h = c && rhs_hoisted(p->rhs) && rhs_hoisted(p->rhs2);
+                        if (!h && p->lhs->hoisted) { p->lhs->hoisted = false; changed = true; }
+                    }
+                    break;
+                }
+                case Stmt::While: {
+                    // the loop condition reads entry phis, so iterate locally
+                    bool c = ctx && rhs_hoisted(s->cond);
+                    for (Stmt *p : s->phis) {
+                        bool h = c && rhs_hoisted(p->rhs) && rhs_hoisted(p->rhs2);
+                        if (!h && p->lhs->hoisted) { p->lhs->hoisted = false; changed = true; }
+                    }
+                    c = ctx && rhs_hoisted(s->cond);
+                    walk(s->body, c);
+                    break;
+                }
+                default: break;
+            }
+        }
+    };
+    while (changed) {
+        changed = false;
+        walk(code.body, true);
+    }
+    // statement slices
+    std::function<void(Block &, bool &, bool &)> mark = [&](Block &b, bool &any_h, bool &any_p) {
+        for (Stmt *s : b) {
+            switch (s->kind) {
+                case Stmt::Assign:
+                case Stmt::Phi:
+                    s->hoisted = s->lhs->hoisted;
+                    s->in_pixel = !s->lhs->hoisted;
+                    break;
+                case Stmt::If: {
+                    bool h = false, p = false;
+                    mark(s->then_, h, p);
+                    mark(s->else_, h, p);
+                    mark(s->phis, h, p);
+                    s->hoisted = h;
+                    s->in_pixel = p;
+                    break;
+                }
+                case Stmt::While: {
+                    bool h = false, p = false;
+                    mark(s->phis, h, p);
+                    mark(s->body, h, p);
+                    s->hoisted = h;
+                    s->in_pixel = p;
+                    // a loop cannot be split: if any of it is per-pixel the whole loop
+                    // (including its frame-constant parts) runs per pixel
+                    if (p && h) {
+                        std::function<void(Block &)> demote = [&](Block &bb) {
+                            for (Stmt *t : bb) {
+                                if (t->kind == Stmt::Assign || t->kind == Stmt::Phi) t->lhs->hoisted = false;
+                                if (t->kind == Stmt::If) { demote(t->then_); demote(t->else_); demote(t->phis); }
+                                if (t->kind == Stmt::While) { demote(t->phis); demote(t->body); }
+                            }
+                        };
+                        demote(s->phis);
+                        demote(s->body);
+                    }
+                    break;
+                }
+                default: break;
+            }
+            any_h |= s->hoisted;
+            any_p |= s->in_pixel;
+        }
+    };
+    // demotion inside mixed loops can invalidate earlier decisions -> iterate
+    for (int iter = 0; iter < 10; ++iter) {
+        bool h = false, p = false;
+        size_t before = 0, after = 0;
+        for (Value &v : code.values) before += v.hoisted;
+        mark(code.body, h, p);
+        changed = true;
+        while (changed) { changed = false; walk(code.body, true); }
+        for (Value &v : code.values) after += v.hoisted;
+        if (before == after) { mark(code.body, h, p); break; }
+    }
+}
+
+}  // namespace mm

@@ -1,0 +1,558 @@
+// C ABI + GPU runtime: hiprtc JIT, HBM-resident images and user values, launches.
+//
+// One mmhip_invocation corresponds to the reference's mathmap_invocation_t
+// (mathmap.h:162-202): canvas/render size, user values, input drawables, edge
+// behaviour.  Rendering a row band = one prologue launch (frame constants, the
+// reference's init_frame, new_template.c.in:314-337) + native-filter kernels if
+// the filter calls any + one pixel-kernel launch (calc_lines, :208-312).
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mmhip.h"
+#include "front.h"
+#include "hipgen.h"
+#include "mm_host_abi.h"
+#include "native_filters.h"
+#include "passes.h"
+
+using namespace mm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg) {
+    g_err = msg;
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+std::string cache_dir() {
+    const char *env = getenv("MMHIP_CACHE_DIR");
+    std::string d = env ? env : "/tmp/mmhip-cache-" + std::to_string((int)getuid());
+    mkdir(d.c_str(), 0700);
+    return d;
+}
+
+}  // namespace
+
+struct mmhip_filter {
+    Module module;
+    std::unique_ptr<FilterCode> code;
+    KernelOptions kopt;
+    KernelSource ks;
+    std::string ir_json;
+    std::vector<char> code_object;
+    hipModule_t mod = nullptr;
+    hipFunction_t f_pro = nullptr, f_pix = nullptr;
+    bool loaded = false;
+    double jit_seconds = 0;
+};
+
+struct mmhip_invocation {
+    mmhip_filter *f = nullptr;
+    int img_w = 0, img_h = 0, render_w = 0, render_h = 0;
+    std::vector<HUserval> uv;
+    std::vector<HImageDesc> images;
+    std::vector<int> image_slot_of_uv;     // userval index -> image table slot (or -1)
+    int native_slot_base = 0;
+    HUserval *d_uv = nullptr;
+    HImageDesc *d_images = nullptr;
+    bool tables_dirty = true;
+    std::vector<void *> owned;             // device buffers we allocated for input images
+    std::vector<void *> native_maps;       // float4 maps produced by native filters
+    std::vector<HNativeRec> native_memo;   // args of the call that produced native_maps[k]
+    std::vector<unsigned long long> native_memo_gen;
+    unsigned long long input_generation = 1;
+    char *d_xy = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t edge_color_x = 0, edge_color_y = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    NativeWorkspace ws;
+};
+
+extern "C" {
+
+const char *mmhip_last_error(void) { return g_err.c_str(); }
+const char *mmhip_version(void) { return "mathmap_amd 0.1 (gfx950)"; }
+
+void mmhip_default_options(mmhip_options *o) {
+    memset(o, 0, sizeof *o);
+    o->intersample = 1;
+    o->tile_w = 0;
+}
+
+mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts) {
+    std::unique_ptr<mmhip_filter> f(new mmhip_filter());
+    try {
+        parse_module(f->module, source);
+        f->code = lower_filter(f->module, f->module.main);
+        optimize(*f->code);
+        analyze_frame_constants(*f->code);
+        KernelOptions ko;
+        if (opts) {
+            ko.intersample = opts->intersample;
+            ko.supersampling = opts->supersampling;
+            ko.edge_x = opts->edge_behaviour_x;
+            ko.edge_y = opts->edge_behaviour_y;
+            if (opts->tile_w) ko.tile_w = opts->tile_w;
+        }
+        f->kopt = ko;
+        f->ir_json = dump_ir(*f->code);
+        f->ks = generate_hip(*f->code, ko);
+    } catch (const CompileError &e) {
+        g_err = e.what();
+        if (e.pos >= 0) g_err += " (at offset " + std::to_string(e.pos) + ")";
+        return nullptr;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+    return f.release();
+}
+
+void mmhip_filter_free(mmhip_filter *f) {
+    if (!f) return;
+    if (f->mod) (void)hipModuleUnload(f->mod);
+    delete f;
+}
+
+const char *mmhip_filter_name(const mmhip_filter *f) { return f->module.main->name.c_str(); }
+int mmhip_filter_num_uservals(const mmhip_filter *f) { return (int)f->module.main->uservals.size(); }
+
+int mmhip_filter_userval_info(const mmhip_filter *f, int index, mmhip_userval_info *out) {
+    const auto &uvs = f->module.main->uservals;
+    if (index < 0 || index >= (int)uvs.size()) return fail("user value index out of range");
+    const UservalInfo &u = uvs[index];
+    memset(out, 0, sizeof *out);
+    out->kind = (int)u.kind;
+    out->index = u.index;
+    snprintf(out->name, sizeof out->name, "%s", u.name.c_str());
+    out->int_min = u.imin; out->int_max = u.imax; out->int_default = u.idef;
+    out->float_min = u.fmin; out->float_max = u.fmax; out->float_default = u.fdef;
+    out->bool_default = u.bdef;
+    out->image_flags = u.image_flags;
+    return 0;
+}
+
+const char *mmhip_filter_ir_json(mmhip_filter *f) { return f->ir_json.c_str(); }
+const char *mmhip_filter_kernel_source(mmhip_filter *f) { return f->ks.source.c_str(); }
+int mmhip_filter_num_native_calls(const mmhip_filter *f) { return (int)f->ks.natives.size(); }
+double mmhip_filter_jit_seconds(const mmhip_filter *f) { return f->jit_seconds; }
+
+long mmhip_filter_jit(mmhip_filter *f, int load_module) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (f->code_object.empty()) {
+        std::string path = cache_dir() + "/" + f->ks.key + ".hsaco";
+        std::ifstream in(path, std::ios::binary);
+        if (in && !getenv("MMHIP_NO_CACHE")) {
+            f->code_object.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+        }
+        if (f->code_object.empty()) {
+            hiprtcProgram prog;
+            if (hiprtcCreateProgram(&prog, f->ks.source.c_str(), "mathmap_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+                return fail("hiprtcCreateProgram failed");
+            const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+            hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+            if (r != HIPRTC_SUCCESS) {
+                size_t n = 0;
+                hiprtcGetProgramLogSize(prog, &n);
+                std::string log(n, 0);
+                if (n) hiprtcGetProgramLog(prog, &log[0]);
+                hiprtcDestroyProgram(&prog);
+                return fail("hiprtc compile failed:\n" + log);
+            }
+            size_t n = 0;
+            hiprtcGetCodeSize(prog, &n);
+            f->code_object.resize(n);
+            hiprtcGetCode(prog, f->code_object.data());
+            hiprtcDestroyProgram(&prog);
+            std::string tmp = path + ".tmp" + std::to_string((int)getpid());
+            std::ofstream o(tmp, std::ios::binary);
+            if (o) {
+                o.write(f->code_object.data(), (std::streamsize)f->code_object.size());
+                o.close();
+                rename(tmp.c_str(), path.c_str());
+            }
+        }
+    }
+    if (load_module && !f->loaded) {
+        hipError_t e = hipModuleLoadData(&f->mod, f->code_object.data());
+        if (e != hipSuccess) return fail(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+        e = hipModuleGetFunction(&f->f_pix, f->mod, f->ks.pixel_name.c_str());
+        if (e != hipSuccess) return fail(std::string("hipModuleGetFunction(pixels): ") + hipGetErrorString(e));
+        e = hipModuleGetFunction(&f->f_pro, f->mod, f->ks.prologue_name.c_str());
+        if (e != hipSuccess) return fail(std::string("hipModuleGetFunction(prologue): ") + hipGetErrorString(e));
+        f->loaded = true;
+    }
+    f->jit_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return (long)f->code_object.size();
+}
+
+// ---------------------------------------------------------------------------
+// invocation
+// ---------------------------------------------------------------------------
+mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
+    if (img_width <= 0 || img_height <= 0) { fail("image size must be positive"); return nullptr; }
+    if (mmhip_filter_jit(f, 1) < 0) return nullptr;
+    std::unique_ptr<mmhip_invocation> inv(new mmhip_invocation());
+    inv->f = f;
+    inv->img_w = inv->render_w = img_width;
+    inv->img_h = inv->render_h = img_height;
+    const auto &uvs = f->module.main->uservals;
+    inv->uv.resize(std::max<size_t>(uvs.size(), 1));
+    inv->image_slot_of_uv.assign(uvs.size(), -1);
+    for (const UservalInfo &u : uvs) {   // defaults: userval.c:361-409
+        HUserval &v = inv->uv[u.index];
+        v.i = 0;
+        switch (u.kind) {
+            case UvKind::Int: v.i = u.idef; break;
+            case UvKind::Float: v.f = u.fdef; break;
+            case UvKind::Bool: v.i = u.bdef ? 1 : 0; break;
+            case UvKind::Color: v.c = 0x000000ffu; break;   // opaque black
+            case UvKind::Curve:
+            case UvKind::Gradient: v.i = 0; break;
+            case UvKind::Image: {
+                int slot = (int)inv->images.size();
+                inv->image_slot_of_uv[u.index] = slot;
+                HImageDesc d{};
+                d.kind = IMG_NULL;
+                inv->images.push_back(d);
+                v.image = slot;
+                break;
+            }
+        }
+    }
+    inv->native_slot_base = (int)inv->images.size();
+    for (size_t k = 0; k < f->ks.natives.size(); ++k) {
+        HImageDesc d{};
+        d.kind = IMG_NULL;
+        inv->images.push_back(d);
+    }
+    inv->native_maps.assign(f->ks.natives.size(), nullptr);
+    inv->native_memo.resize(f->ks.natives.size());
+    inv->native_memo_gen.assign(f->ks.natives.size(), 0);
+    if (inv->images.empty()) { HImageDesc d{}; d.kind = IMG_NULL; inv->images.push_back(d); }
+    auto bail = [&](const char *what, hipError_t e) -> mmhip_invocation * {
+        fail(std::string(what) + ": " + hipGetErrorString(e));
+        return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipStreamCreate(&inv->stream)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipMalloc((void **)&inv->d_uv, inv->uv.size() * sizeof(HUserval))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&inv->d_images, inv->images.size() * sizeof(HImageDesc))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&inv->d_xy, f->ks.xy_bytes)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(inv->d_xy, 0, f->ks.xy_bytes)) != hipSuccess) return bail("hipMemset", e);
+    return inv.release();
+}
+
+void mmhip_invocation_free(mmhip_invocation *inv) {
+    if (!inv) return;
+    if (inv->stream) (void)hipStreamSynchronize(inv->stream);
+    for (void *p : inv->owned) (void)hipFree(p);
+    for (void *p : inv->native_maps) if (p) (void)hipFree(p);
+    inv->ws.release();
+    if (inv->d_uv) (void)hipFree(inv->d_uv);
+    if (inv->d_images) (void)hipFree(inv->d_images);
+    if (inv->d_xy) (void)hipFree(inv->d_xy);
+    if (inv->ev0) (void)hipEventDestroy(inv->ev0);
+    if (inv->ev1) (void)hipEventDestroy(inv->ev1);
+    if (inv->stream) (void)hipStreamDestroy(inv->stream);
+    delete inv;
+}
+
+static const UservalInfo *uv_info(mmhip_invocation *inv, int index, UvKind kind) {
+    const auto &uvs = inv->f->module.main->uservals;
+    if (index < 0 || index >= (int)uvs.size()) { fail("user value index out of range"); return nullptr; }
+    if (uvs[index].kind != kind) { fail("user value `" + uvs[index].name + "' has a different type"); return nullptr; }
+    return &uvs[index];
+}
+
+int mmhip_set_int(mmhip_invocation *inv, int index, int value) {
+    const UservalInfo *u = uv_info(inv, index, UvKind::Int);
+    if (!u) return -1;
+    inv->uv[index].i = value;
+    inv->tables_dirty = true;
+    return 0;
+}
+
+int mmhip_set_float(mmhip_invocation *inv, int index, float value) {
+    const UservalInfo *u = uv_info(inv, index, UvKind::Float);
+    if (!u) return -1;
+    inv->uv[index].f = value;
+    inv->tables_dirty = true;
+    return 0;
+}
+
+int mmhip_set_bool(mmhip_invocation *inv, int index, int value) {
+    const UservalInfo *u = uv_info(inv, index, UvKind::Bool);
+    if (!u) return -1;
+    inv->uv[index].i = value ? 1 : 0;
+    inv->tables_dirty = true;
+    return 0;
+}
+
+int mmhip_set_color(mmhip_invocation *inv, int index, float r, float g, float b, float a) {
+    const UservalInfo *u = uv_info(inv, index, UvKind::Color);
+    if (!u) return -1;
+    auto q = [](float v) { v = v < 0 ? 0 : v > 1 ? 1 : v; return (uint32_t)(v * 255.0); };
+    inv->uv[index].c = (q(r) << 24) | (q(g) << 16) | (q(b) << 8) | q(a);
+    inv->tables_dirty = true;
+    return 0;
+}
+
+// -Dname=value (mathmap_cmdline.c:756-796; images are bound by the caller)
+int mmhip_set_by_name(mmhip_invocation *inv, const char *name, const char *value) {
+    for (const UservalInfo &u : inv->f->module.main->uservals) {
+        if (u.name != name) continue;
+        switch (u.kind) {
+            case UvKind::Int: return mmhip_set_int(inv, u.index, atoi(value));
+            case UvKind::Float: return mmhip_set_float(inv, u.index, (float)atof(value));
+            case UvKind::Bool: return mmhip_set_bool(inv, u.index, atoi(value));
+            default: return fail(std::string("user value `") + name + "' cannot be set from a string");
+        }
+    }
+    return fail(std::string("filter has no user value `") + name + "'");
+}
+
+static void fill_drawable_desc(HImageDesc &d, const void *data, int w, int h) {
+    d.data = data;
+    d.w = w;
+    d.h = h;
+    d.kind = IMG_DRAWABLE;
+    d.num_frames = 1;
+    d.scale_x = (float)((w - 1) / 2.0);    // userval.c:272-276
+    d.scale_y = (float)((h - 1) / 2.0);
+    d.middle_x = 1.0f;
+    d.middle_y = 1.0f;
+    d.ax = d.bx = d.ay = d.by = 0.f;
+}
+
+int mmhip_set_image_device(mmhip_invocation *inv, int index, const void *device_rgba32, int width, int height) {
+    const UservalInfo *u = uv_info(inv, index, UvKind::Image);
+    if (!u) return -1;
+    int slot = inv->image_slot_of_uv[index];
+    fill_drawable_desc(inv->images[slot], device_rgba32, width, height);
+    inv->tables_dirty = true;
+    ++inv->input_generation;
+    return 0;
+}
+
+int mmhip_set_image_host(mmhip_invocation *inv, int index, const uint8_t *pixels, int width, int height, int channels) {
+    if (channels != 3 && channels != 4) return fail("channels must be 3 or 4");
+    if (!uv_info(inv, index, UvKind::Image)) return -1;
+    size_t n = (size_t)width * height;
+    std::vector<uint32_t> packed(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t *p = pixels + i * channels;
+        uint32_t a = channels == 4 ? p[3] : 255u;
+        packed[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | a;
+    }
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, n * 4));
+    HIP_TRY(hipMemcpy(d, packed.data(), n * 4, hipMemcpyHostToDevice));
+    inv->owned.push_back(d);
+    return mmhip_set_image_device(inv, index, d, width, height);
+}
+
+int mmhip_set_edge_colors(mmhip_invocation *inv, uint32_t cx, uint32_t cy) {
+    inv->edge_color_x = cx;
+    inv->edge_color_y = cy;
+    return 0;
+}
+
+int mmhip_set_render_size(mmhip_invocation *inv, int rw, int rh) {
+    inv->render_w = rw;
+    inv->render_h = rh;
+    return 0;
+}
+
+int mmhip_enable_timing(mmhip_invocation *inv, int on) {
+    inv->timing = on != 0;
+    if (on && !inv->ev0) {
+        HIP_TRY(hipEventCreate(&inv->ev0));
+        HIP_TRY(hipEventCreate(&inv->ev1));
+    }
+    return 0;
+}
+
+double mmhip_last_kernel_ms(mmhip_invocation *inv) {
+    if (!inv->ev_valid) return -1.0;
+    if (hipEventSynchronize(inv->ev1) != hipSuccess) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, inv->ev0, inv->ev1) != hipSuccess) return -1.0;
+    return ms;
+}
+
+static int upload_tables(mmhip_invocation *inv, hipStream_t s) {
+    if (!inv->tables_dirty) return 0;
+    // make sure nothing in flight still reads the old tables
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(inv->d_uv, inv->uv.data(), inv->uv.size() * sizeof(HUserval), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(inv->d_images, inv->images.data(), inv->images.size() * sizeof(HImageDesc), hipMemcpyHostToDevice));
+    inv->tables_dirty = false;
+    return 0;
+}
+
+static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
+    mmhip_filter *f = inv->f;
+    std::vector<char> host(f->ks.xy_bytes);
+    HIP_TRY(hipMemcpyAsync(host.data(), inv->d_xy, host.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool table_changed = false;
+    for (size_t k = 0; k < f->ks.natives.size(); ++k) {
+        HNativeRec rec;
+        memcpy(&rec, host.data() + f->ks.natives[k].record_offset, sizeof rec);
+        if (!rec.executed) continue;
+        int slot = inv->native_slot_base + (int)k;
+        // memo (native-filters/cache.c:110-147): same arguments on unchanged inputs -> keep the map
+        if (inv->native_maps[k] && inv->native_memo_gen[k] == inv->input_generation &&
+            memcmp(&inv->native_memo[k], &rec, sizeof rec) == 0)
+            continue;
+        size_t bytes = (size_t)a.render_width * a.render_height * 16;
+        if (!inv->native_maps[k]) HIP_TRY(hipMalloc(&inv->native_maps[k], bytes));
+        std::string err;
+        int rc = run_native_filter(f->ks.natives[k].func, rec, inv->images, a.render_width, a.render_height,
+                                   (float *)inv->native_maps[k], inv->ws, s, &err);
+        if (rc != 0) return fail(err);
+        HImageDesc &d = inv->images[slot];
+        d.data = inv->native_maps[k];
+        d.w = a.render_width;
+        d.h = a.render_height;
+        d.kind = IMG_FLOATMAP;
+        d.num_frames = 1;
+        d.ax = d.bx = (float)((float)(d.w - 1) / 2.0);     // floatmap.c:39-41
+        d.ay = d.by = (float)((float)(d.h - 1) / 2.0);
+        d.ay *= -1.0f;
+        inv->native_memo[k] = rec;
+        inv->native_memo_gen[k] = inv->input_generation;
+        table_changed = true;
+    }
+    if (table_changed) {
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(inv->d_images, inv->images.data(), inv->images.size() * sizeof(HImageDesc), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
+                 int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream) {
+    mmhip_filter *f = inv->f;
+    hipStream_t s = stream ? (hipStream_t)stream : inv->stream;
+    if (bpp < 1 || bpp > 4) return fail("output_bpp must be 1..4");
+    if (region_w <= 0 || region_h <= 0) return fail("empty region");
+    // new_template.c.in:238-239
+    if (first_row < 0) first_row = 0;
+    if (last_row > region_y + region_h) last_row = region_y + region_h;
+    if (last_row <= first_row) return 0;
+    if (upload_tables(inv, s) != 0) return -1;
+
+    HArgs a{};
+    a.img_width = inv->img_w;
+    a.img_height = inv->img_h;
+    a.render_width = inv->render_w;
+    a.render_height = inv->render_h;
+    a.frame_render_width = inv->render_w;     // invocation_new_frame, mathmap_common.c:805-806
+    a.frame_render_height = inv->render_h;
+    a.t = t;
+    a.frame = frame;
+    a.R = (float)sqrt(2.0);                   // mathmap_common.c:770
+    a.region_x = region_x;
+    a.region_y = region_y;
+    a.region_width = region_w;
+    a.region_height = region_h;
+    a.sampling_offset_x = 0.f;
+    a.sampling_offset_y = 0.f;
+    a.first_row = first_row;
+    a.num_rows = last_row - first_row;
+    a.output_bpp = bpp;
+    a.row_stride = row_stride;
+    a.floatmap = floatmap;
+    a.edge_color_x = inv->edge_color_x;
+    a.edge_color_y = inv->edge_color_y;
+    a.uservals = inv->d_uv;
+    a.images = inv->d_images;
+    a.curves = nullptr;
+    a.gradients = nullptr;
+    a.out = out_device;
+    a.native_slot_base = inv->native_slot_base;
+
+    char *xy = inv->d_xy;
+    void *params[] = {&a, &xy};
+    if (f->ks.has_prologue) {
+        HIP_TRY(hipModuleLaunchKernel(f->f_pro, 1, 1, 1, 64, 1, 1, 0, s, params, nullptr));
+        if (!f->ks.natives.empty() && run_natives(inv, a, s) != 0) return -1;
+    }
+    int tiles_x = (region_w + f->ks.tile_w - 1) / f->ks.tile_w;
+    int tiles_y = (a.num_rows + f->ks.tile_h - 1) / f->ks.tile_h;
+    long nwg = (long)tiles_x * tiles_y;
+    if (nwg > 0x7fffffffL) return fail("region too large for one launch");
+    if (inv->timing) HIP_TRY(hipEventRecord(inv->ev0, s));
+    HIP_TRY(hipModuleLaunchKernel(f->f_pix, (unsigned)nwg, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+    if (inv->timing) {
+        HIP_TRY(hipEventRecord(inv->ev1, s));
+        inv->ev_valid = true;
+    }
+    return 0;
+}
+
+int mmhip_sync(mmhip_invocation *inv) {
+    HIP_TRY(hipStreamSynchronize(inv->stream));
+    return 0;
+}
+
+int mmhip_render_host(mmhip_invocation *inv, int frame, float t, uint8_t *out_rgba) {
+    size_t bytes = (size_t)inv->render_w * inv->render_h * 4;
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    int rc = mmhip_render(inv, frame, t, 0, 0, inv->render_w, inv->render_h, 0, inv->render_h, d, inv->render_w * 4, 4, 0,
+                          nullptr);
+    if (rc == 0) {
+        hipError_t e = hipStreamSynchronize(inv->stream);
+        if (e == hipSuccess) e = hipMemcpy(out_rgba, d, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(std::string("render: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+void *mmhip_device_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { fail("hipMalloc failed"); return nullptr; }
+    return p;
+}
+void mmhip_device_free(void *p) { (void)hipFree(p); }
+int mmhip_copy_to_host(void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int mmhip_copy_to_device(void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int mmhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

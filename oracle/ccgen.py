@@ -1,0 +1,454 @@
+"""CPU ORACLE (test infrastructure, NOT product code): IR -> C, like the reference's cc backend.
+
+Takes the IR dump of a compiled filter (``mmhip_filter_ir_json``) and prints it as C in
+the shape the reference's ``backends/cc.c`` + ``new_template.c.in`` produce:
+
+* one C variable per SSA value, phi copies at the end of branches / loop bodies
+  (cc.c:308-397);
+* ``init_frame`` evaluating the frame-constant statements once into an ``xy_vars``
+  struct (new_template.c.in:314-337) and ``calc_lines`` with the row/column double loop,
+  ``CALC_VIRTUAL_X/Y`` in double and the byte packing of new_template.c.in:243-309.
+
+The text is compiled exactly as the reference compiles its generated code --
+``gcc -O2 -c -fPIC`` + ``gcc -shared`` (reference Makefile:58-60, cc.c:673-681) -- and
+linked with oracle/mm_oracle_rt.c.  libm / complex libm calls go to the host's glibc
+just as in the reference.  This is the "port" CPU baseline of bench.py and the checker
+of the parity tests; it is an independent second implementation of statement printing
+(the product's is mathmap_amd/csrc/hipgen.cpp).
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import struct
+import subprocess
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+
+CTYPES = {"int": "int", "float": "float", "complex": "float _Complex", "color": "color_t",
+          "curve": "int", "gradient": "int", "image": "mmo_image"}
+
+UNSUPPORTED = {"RAND", "ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P", "ELL_INT_D",
+               "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ", "ELL_JAC", "SOLVE_LINEAR_2",
+               "SOLVE_LINEAR_3", "SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH",
+               "libnoise_perlin", "libnoise_billow", "libnoise_ridged_multi", "libnoise_voronoi"}
+
+
+class OracleUnsupported(Exception):
+    pass
+
+
+def _float_literal(bits):
+    f = struct.unpack("<f", struct.pack("<I", bits))[0]
+    if f != f:
+        return "(0.0/0.0)"
+    if f in (float("inf"), float("-inf")):
+        return "(1.0/0.0)" if f > 0 else "(-1.0/0.0)"
+    s = repr(float(f))
+    if "." not in s and "e" not in s and "n" not in s:
+        s += ".0"
+    return "(%s)" % s if s.startswith("-") else s
+
+
+class Gen:
+    def __init__(self, ir):
+        self.ir = ir
+        self.vars = {v["id"]: v for v in ir["vars"]}
+        self.natives = {}      # id(stmt) -> slot
+        self.nnative = 0
+        self._find_natives(ir["body"])
+
+    # same traversal order as hipgen.cpp:find_natives so slot numbers agree
+    def _find_natives(self, block):
+        for s in block:
+            if s["k"] == "assign":
+                r = s["rhs"]
+                if (r["k"] == "closure" and r["native"]) or (r["k"] == "op" and r["op"] == "RENDER"):
+                    self.natives[id(s)] = self.nnative
+                    self.nnative += 1
+            elif s["k"] == "if":
+                self._find_natives(s["then"])
+                self._find_natives(s["else"])
+            elif s["k"] == "while":
+                self._find_natives(s["body"])
+
+    def ctype(self, vid):
+        v = self.vars[vid]
+        if v["type"] == "tuple":
+            return "mmo_tup%d" % (v["tuple_len"] or 4)
+        return CTYPES[v["type"]]
+
+    def vname(self, vid, idx):
+        return "v%d_%d" % (vid, idx)
+
+    def prim(self, p):
+        k = p[0]
+        if k == "v":
+            vid, idx = p[1], p[2]
+            if idx < 0:
+                t = self.vars[vid]["type"]
+                if t == "image":
+                    return "UNINITED_IMAGE"
+                if t == "tuple":
+                    return "(%s){{0}}" % self.ctype(vid)
+                return "0"
+            return self.vname(vid, idx)
+        if k == "i":
+            return "(%d)" % p[1] if p[1] < 0 else str(p[1])
+        if k == "f":
+            return _float_literal(p[1])
+        if k == "c":
+            return "COMPLEX(%s,%s)" % (_float_literal(p[1]), _float_literal(p[2]))
+        if k == "k":
+            return "%du" % p[1]
+        raise ValueError(p)
+
+    def rhs(self, r, stmt=None):
+        k = r["k"]
+        if k == "prim":
+            return self.prim(r["p"])
+        if k == "internal":
+            return r["name"]
+        if k == "tuple":
+            return "(mmo_tup%d){{%s}}" % (len(r["args"]), ", ".join(self.prim(a) for a in r["args"]))
+        if k == "closure":
+            if not r["native"]:
+                return "mmo_closure_image(A)"
+            slot = self.natives[id(stmt)]
+            args = ", ".join(self.prim(a) for a in r["args"])
+            fn = {"native_filter_gaussian_blur": "mmo_native_gaussian_blur"}.get(r["native"])
+            if fn is None:
+                raise OracleUnsupported("native filter %s" % r["native"])
+            return "%s(A, %d, %s)" % (fn, slot, args)
+        if k == "op":
+            op = r["op"]
+            if op in UNSUPPORTED:
+                raise OracleUnsupported("op %s" % op)
+            if op == "RENDER":
+                return "mmo_render(A, %d, %s)" % (self.natives[id(stmt)], ", ".join(self.prim(a) for a in r["args"]))
+            return "%s(%s)" % (op, ",".join(self.prim(a) for a in r["args"]))
+        raise OracleUnsupported("rhs kind %s" % k)
+
+    # ---- slices ------------------------------------------------------------------
+    def mine(self, s, hoisted):
+        return s["hoisted"] if hoisted else s["pixel"]
+
+    def collect(self, block, hoisted, defs, uses):
+        def use(r):
+            if r is None:
+                return
+            if r["k"] == "prim" and r["p"][0] == "v":
+                uses.add((r["p"][1], r["p"][2]))
+            for a in r.get("args", []):
+                if a[0] == "v":
+                    uses.add((a[1], a[2]))
+        for s in block:
+            if not self.mine(s, hoisted):
+                continue
+            if s["k"] == "assign":
+                defs.append(tuple(s["lhs"]))
+                use(s["rhs"])
+            elif s["k"] == "if":
+                use(s["cond"])
+                self.collect(s["then"], hoisted, defs, uses)
+                self.collect(s["else"], hoisted, defs, uses)
+                self.collect_phis(s["phis"], hoisted, defs, uses, use)
+            elif s["k"] == "while":
+                self.collect_phis(s["phis"], hoisted, defs, uses, use)
+                use(s["cond"])
+                self.collect(s["body"], hoisted, defs, uses)
+
+    def collect_phis(self, phis, hoisted, defs, uses, use):
+        for p in phis:
+            if self.mine(p, hoisted):
+                defs.append(tuple(p["lhs"]))
+                use(p["rhs"])
+                use(p["rhs2"])
+
+    def phis(self, phis, branch, hoisted, ind, out):
+        mine = []
+        for p in phis:
+            if not self.mine(p, hoisted):
+                continue
+            r = p["rhs"] if branch == 0 else p["rhs2"]
+            if r["k"] == "prim" and r["p"][0] == "v" and [r["p"][1], r["p"][2]] == p["lhs"]:
+                continue
+            mine.append((p, r))
+        targets = {tuple(p["lhs"]) for p, _ in mine}
+        hazard = any(r["k"] == "prim" and r["p"][0] == "v" and (r["p"][1], r["p"][2]) in targets for _, r in mine)
+        if not hazard:
+            for p, r in mine:
+                out.append("%s%s = %s;" % (ind, self.vname(*p["lhs"]), self.rhs(r)))
+            return
+        out.append(ind + "{")
+        for i, (p, r) in enumerate(mine):
+            out.append("%s  %s pc%d = %s;" % (ind, self.ctype(p["lhs"][0]), i, self.rhs(r)))
+        for i, (p, r) in enumerate(mine):
+            out.append("%s  %s = pc%d;" % (ind, self.vname(*p["lhs"]), i))
+        out.append(ind + "}")
+
+    def stmts(self, block, hoisted, ind, out):
+        for s in block:
+            if not self.mine(s, hoisted):
+                continue
+            if s["k"] == "assign":
+                out.append("%s%s = %s;" % (ind, self.vname(*s["lhs"]), self.rhs(s["rhs"], s)))
+            elif s["k"] == "if":
+                out.append("%sif (%s) {" % (ind, self.rhs(s["cond"])))
+                self.stmts(s["then"], hoisted, ind + "  ", out)
+                self.phis(s["phis"], 0, hoisted, ind + "  ", out)
+                out.append(ind + "} else {")
+                self.stmts(s["else"], hoisted, ind + "  ", out)
+                self.phis(s["phis"], 1, hoisted, ind + "  ", out)
+                out.append(ind + "}")
+            elif s["k"] == "while":
+                self.phis(s["phis"], 0, hoisted, ind, out)
+                out.append("%swhile (%s) {" % (ind, self.rhs(s["cond"])))
+                self.stmts(s["body"], hoisted, ind + "  ", out)
+                self.phis(s["phis"], 1, hoisted, ind + "  ", out)
+                out.append(ind + "}")
+
+    def decls(self, defs, ind, out, skip=()):
+        seen = set()
+        for d in defs:
+            if d in seen or d[1] < 0 or d in skip:
+                continue
+            seen.add(d)
+            t = self.ctype(d[0])
+            init = " = 0" if t in ("int", "float", "color_t") else ""
+            out.append("%s%s %s%s;" % (ind, t, self.vname(*d), init))
+
+    def source(self):
+        ir = self.ir
+        pro_defs, pro_uses, pix_defs, pix_uses = [], set(), [], set()
+        self.collect(ir["body"], True, pro_defs, pro_uses)
+        self.collect(ir["body"], False, pix_defs, pix_uses)
+        for r in ir["result"]:
+            pix_uses.add(tuple(r))
+        pix_def_set = set(pix_defs)
+        transfers = []
+        for d in pro_defs:
+            if d in pix_uses and d not in pix_def_set and d not in transfers:
+                transfers.append(d)
+        out = ['#include "mm_oracle.h"', "", "typedef struct {"]
+        for d in transfers:
+            out.append("  %s %s;" % (self.ctype(d[0]), self.vname(*d)))
+        out.append("  int unused_;")
+        out.append("} xy_vars_t;")
+        out.append("""
+#define MMO_INTERNALS \\
+    const float t = A->t; const float R = A->R; const int frame = A->frame; \\
+    const int __canvasPixelW = A->img_width, __canvasPixelH = A->img_height; \\
+    const int __renderPixelW = A->render_width, __renderPixelH = A->render_height; \\
+    (void)t; (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;
+
+int mmo_xy_size(void) { return (int)sizeof(xy_vars_t); }
+int mmo_num_natives(void) { return %d; }
+
+void mmo_init_frame(const mmo_args *A, void *xyv) {
+  xy_vars_t *xy_vars = (xy_vars_t *)xyv;
+  MMO_INTERNALS""" % self.nnative)
+        self.decls(pro_defs, "  ", out)
+        self.stmts(ir["body"], True, "  ", out)
+        for d in transfers:
+            out.append("  xy_vars->%s = %s;" % (self.vname(*d), self.vname(*d)))
+        out.append("  (void)xy_vars;\n}\n")
+        out.append("""void mmo_calc_lines(const mmo_args *A, const void *xyv, int first_row, int last_row, void *q) {
+  const xy_vars_t *xy_vars = (const xy_vars_t *)xyv;
+  MMO_INTERNALS
+  int row, col;
+  first_row = MAX(0, first_row);
+  last_row = MIN(last_row, A->region_y + A->region_height);""")
+        for d in transfers:
+            out.append("  const %s %s = xy_vars->%s;" % (self.ctype(d[0]), self.vname(*d), self.vname(*d)))
+        out.append("""  (void)xy_vars;
+  for (row = first_row - A->region_y; row < last_row - A->region_y; ++row) {
+    float y = CALC_VIRTUAL_Y(row + A->region_y, A->frame_render_height, A->sampling_offset_y);
+    unsigned char *p = q;
+    float *fp = q;
+    for (col = 0; col < A->region_width; ++col) {
+      float x = CALC_VIRTUAL_X(col + A->region_x, A->frame_render_width, A->sampling_offset_x);
+      float rt[4];
+      (void)x; (void)y;""")
+        self.decls(pix_defs, "      ", out)
+        self.stmts(ir["body"], False, "      ", out)
+        for i, r in enumerate(ir["result"]):
+            out.append("      rt[%d] = %s;" % (i, self.prim(["v", r[0], r[1]])))
+        out.append("""      mmo_store_pixel(A, p, fp, rt);
+      p += A->output_bpp;
+      fp += 4;
+    }
+    if (A->floatmap) q = (float *)q + A->frame_render_width * 4;
+    else q = (unsigned char *)q + A->row_stride;
+  }
+}""")
+        return "\n".join(out) + "\n"
+
+
+# ---------------------------------------------------------------------------------
+# build + run
+# ---------------------------------------------------------------------------------
+class _ImageDesc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("w", C.c_int), ("h", C.c_int), ("kind", C.c_int), ("num_frames", C.c_int),
+                ("channels", C.c_int), ("scale_x", C.c_float), ("scale_y", C.c_float), ("middle_x", C.c_float),
+                ("middle_y", C.c_float), ("ax", C.c_float), ("bx", C.c_float), ("ay", C.c_float), ("by", C.c_float)]
+
+
+class _Memo(C.Structure):
+    _fields_ = [("valid", C.c_int), ("func", C.c_int), ("in_idx", C.c_int), ("a1", C.c_float), ("a2", C.c_float),
+                ("map", C.c_void_p), ("w", C.c_int), ("h", C.c_int)]
+
+
+class _Userval(C.Union):
+    _fields_ = [("i", C.c_int), ("f", C.c_float), ("c", C.c_uint), ("image", C.c_int)]
+
+
+class _Args(C.Structure):
+    _fields_ = [("img_width", C.c_int), ("img_height", C.c_int), ("render_width", C.c_int), ("render_height", C.c_int),
+                ("frame_render_width", C.c_int), ("frame_render_height", C.c_int), ("t", C.c_float),
+                ("frame", C.c_int), ("R", C.c_float), ("region_x", C.c_int), ("region_y", C.c_int),
+                ("region_width", C.c_int), ("region_height", C.c_int), ("sampling_offset_x", C.c_float),
+                ("sampling_offset_y", C.c_float), ("output_bpp", C.c_int), ("row_stride", C.c_int),
+                ("floatmap", C.c_int), ("intersample", C.c_int), ("supersampling", C.c_int),
+                ("edge_behaviour_x", C.c_int), ("edge_behaviour_y", C.c_int), ("edge_color_x", C.c_uint),
+                ("edge_color_y", C.c_uint), ("uservals", C.POINTER(_Userval)), ("images", C.POINTER(_ImageDesc)),
+                ("num_images", C.c_int), ("native_slot_base", C.c_int), ("memo", C.POINTER(_Memo)),
+                ("curves", C.c_void_p), ("gradients", C.c_void_p)]
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("%s failed:\n%s" % (" ".join(cmd), r.stdout))
+
+
+def build_runtime():
+    """Compiles oracle/mm_oracle_rt.c once (gcc -O2 -fPIC, like the reference's own objects)."""
+    os.makedirs(BUILD, exist_ok=True)
+    obj = os.path.join(BUILD, "mm_oracle_rt.o")
+    src = os.path.join(HERE, "mm_oracle_rt.c")
+    hdr = os.path.join(HERE, "mm_oracle.h")
+    if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-o", obj, src])
+    return obj
+
+
+class CpuFilter:
+    """A filter compiled by the oracle's cc-equivalent path."""
+
+    def __init__(self, ir_json):
+        self.ir = json.loads(ir_json) if isinstance(ir_json, str) else ir_json
+        gen = Gen(self.ir)
+        self.source = gen.source()
+        self.nnative = gen.nnative
+        key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+        rt = build_runtime()
+        so = os.path.join(BUILD, "f_%s.so" % key)
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(rt):
+            cfile = os.path.join(BUILD, "f_%s.c" % key)
+            ofile = os.path.join(BUILD, "f_%s.o" % key)
+            with open(cfile, "w") as f:
+                f.write(self.source)
+            # the reference's CGEN_CC / CGEN_LD (Makefile:58-60)
+            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE, "-o", ofile, cfile])
+            _run(["gcc", "-shared", "-o", so + ".tmp", ofile, rt, "-lm"])
+            os.replace(so + ".tmp", so)
+        self.lib = C.CDLL(so)
+        self.lib.mmo_xy_size.restype = C.c_int
+        self.lib.mmo_init_frame.argtypes = [C.POINTER(_Args), C.c_void_p]
+        self.lib.mmo_calc_lines.argtypes = [C.POINTER(_Args), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.mmo_free_memo.argtypes = [C.POINTER(_Args), C.c_int]
+
+    def render(self, width, height, uservals=None, images=None, t=0.0, frame=0, intersample=True, threads=1,
+               bpp=4, floatmap=False, edge=(0, 0), edge_colors=(0, 0), rows=None, timing=None):
+        """Renders on the CPU.  `uservals`: {name: value}; `images`: {name: uint8 [H,W,3|4]}.
+        `threads` > 1 splits the rows into contiguous bands like call_invocation_parallel
+        (mathmap_common.c:972-1006).  Returns uint8 [H,W,bpp] or float32 [H,W,4]."""
+        import time
+        uservals = uservals or {}
+        images = images or {}
+        infos = self.ir["uservals"]
+        n_uv = max(len(infos), 1)
+        uv = (_Userval * n_uv)()
+        descs = []
+        keep = []
+        for u in infos:
+            k, i, name = u["kind"], u["index"], u["name"]
+            if k == 0:
+                uv[i].i = int(uservals.get(name, u["idef"]))
+            elif k == 1:
+                uv[i].f = float(uservals.get(name, np.float32(u["fdef"])))
+            elif k == 2:
+                uv[i].i = int(bool(uservals.get(name, u["bdef"])))
+            elif k == 3:
+                col = uservals.get(name, (0.0, 0.0, 0.0, 1.0))
+                q = [int(min(max(c, 0.0), 1.0) * 255.0) for c in col]
+                uv[i].c = (q[0] << 24) | (q[1] << 16) | (q[2] << 8) | q[3]
+            elif k == 6:
+                d = _ImageDesc()
+                if name in images:
+                    a = np.ascontiguousarray(images[name], dtype=np.uint8)
+                    keep.append(a)
+                    h, w, c = a.shape
+                    d.data, d.w, d.h, d.kind, d.num_frames, d.channels = a.ctypes.data, w, h, 0, 1, c
+                    d.scale_x = np.float32((w - 1) / 2.0)
+                    d.scale_y = np.float32((h - 1) / 2.0)
+                    d.middle_x = d.middle_y = 1.0
+                else:
+                    d.kind = 2
+                uv[i].image = len(descs)
+                descs.append(d)
+            else:
+                uv[i].i = 0
+        nbase = len(descs)
+        for _ in range(self.nnative):
+            d = _ImageDesc()
+            d.kind = 2
+            descs.append(d)
+        if not descs:
+            d = _ImageDesc()
+            d.kind = 2
+            descs.append(d)
+        dtab = (_ImageDesc * len(descs))(*descs)
+        memo = (_Memo * max(self.nnative, 1))()
+        a = _Args()
+        a.img_width = a.render_width = a.frame_render_width = width
+        a.img_height = a.render_height = a.frame_render_height = height
+        a.t, a.frame, a.R = t, frame, np.float32(np.sqrt(2.0))
+        a.region_x = a.region_y = 0
+        a.region_width, a.region_height = width, height
+        a.output_bpp, a.row_stride, a.floatmap = bpp, width * bpp, 1 if floatmap else 0
+        a.intersample, a.supersampling = 1 if intersample else 0, 0
+        a.edge_behaviour_x, a.edge_behaviour_y = edge
+        a.edge_color_x, a.edge_color_y = edge_colors
+        a.uservals, a.images, a.num_images, a.native_slot_base, a.memo = uv, dtab, len(descs), nbase, memo
+        out = np.zeros((height, width, 4), np.float32) if floatmap else np.zeros((height, width, bpp), np.uint8)
+        xy = C.create_string_buffer(max(self.lib.mmo_xy_size(), 16))
+        r0, r1 = rows if rows is not None else (0, height)
+        t0 = time.perf_counter()
+        self.lib.mmo_init_frame(C.byref(a), xy)
+        stride = out.strides[0]
+
+        def band(lo, hi):
+            self.lib.mmo_calc_lines(C.byref(a), xy, lo, hi, C.c_void_p(out.ctypes.data + lo * stride))
+        if threads <= 1:
+            band(r0, r1)
+        else:
+            ths = []
+            n = r1 - r0
+            for k in range(threads):
+                lo, hi = r0 + n * k // threads, r0 + n * (k + 1) // threads
+                th = threading.Thread(target=band, args=(lo, hi))
+                th.start()
+                ths.append(th)
+            for th in ths:
+                th.join()
+        if timing is not None:
+            timing.append(time.perf_counter() - t0)
+        self.lib.mmo_free_memo(C.byref(a), self.nnative)
+        del keep
+        return out
