@@ -1,0 +1,359 @@
+"""The benchmark / parity workloads, written in the .mm filter language.
+
+These are this project's own statements of the five BASELINE.json configurations
+(the reference keeps equivalent scripts under examples/; tests/test_workloads.py
+checks, where the reference tree is available, that each text below compiles to
+code whose output is identical to the reference script's).  User-value names are
+kept because they are the filters' public interface (``-Dname=value``).
+"""
+
+# config 0: examples/Utilities/Ident -- plumbing: output = input sampled at xy
+IDENT = """
+filter ident (image in)
+  in(xy)
+end
+"""
+
+# config 1: examples/Render/Mandelbrot -- quaternion z -> z*z + p escape-time
+# iteration, grey level = iterations / num_iterations
+MANDELBROT = """
+filter mandelbrot (float pj: -2-2 (0), float pk: -2-2 (0),
+                   float c1: -2-2 (0), float ci: -2-2 (0), float cj: -2-2 (0), float ck: -2-2 (0),
+                   int num_iterations: 2-256 (32))
+  pos = ri:xy;
+  offset = quat:[pos[0], pos[1], pj, pk];
+  z = quat:[c1, ci, cj, ck];
+  n = 0;
+  while abs(z) < 2 && n < (num_iterations - 1) do
+    z = z * z + offset;
+    n = n + 1
+  end;
+  grayColor(n / num_iterations)
+end
+"""
+
+# config 4: examples/Distorts/Pond -- radial sine displacement animated by t
+POND = """
+filter pond (image in, float height: 0-1 (0.05), float wavelength: 0-1 (0.04))
+  in(ra + ra:[sin(r / wavelength + t * 2 * pi) * height, 0])
+end
+"""
+
+# config 3: examples/Blur/Gaussian Blur -- native gaussian_blur with the deviation given
+# as a fraction of the larger image dimension
+GAUSSIAN_BLUR = """
+stretched filter gaussian (stretched image in, float dev: 0 - 0.5)
+  px = pixelSize(in);
+  longest = max(px[0], px[1]);
+  soft = gaussian_blur(in, dev * longest / px[0], dev * longest / px[1]);
+  soft(xy)
+end
+"""
+
+# native gaussian_blur with the two deviations passed straight through (bench: sigma in
+# pixels = dev * (W-1)/2, native-filters/gauss.c:659-660)
+GAUSS_DIRECT = """
+stretched filter gauss_direct (stretched image in, float hdev: 0-1 (0.01), float vdev: 0-1 (0.01))
+  soft = gaussian_blur(in, hdev, vdev);
+  soft(xy)
+end
+"""
+
+# config 2: examples/Map/Droste -- Escher's Droste effect (log-polar twist of an annulus,
+# after the Leys / Breic formulation used by the reference example).
+DROSTE = """
+pixel
+filter droste (pixel image in,
+    float InnerRadius: 1 - 100 (25), int OuterRadius: 1 - 100 (100),
+    float Periodicity: -6 - 6 (1), int Strands: -6 - 6 (1),
+    int Zoom: 1-100 (1), int Rotate: -360-360 (0),
+    int XShift: -100 - 100 (0), int YShift: -100 - 100 (0),
+    int XCenterShift: -100 - 100 (0), int YCenterShift: -100 - 100 (0),
+    int StartingLevel: 1-20 (1), int NumberOfLevels: 1-20 (10), int LevelFrequency: 1-10 (1),
+    bool ShowBothPoles, int PoleRotation: -180-180 (90), int PoleLong: -100-100 (0), int PoleLat: -100-100 (0),
+    bool TilePoles, bool HyperDroste, int FractalPoints: 1-10 (1),
+    bool AutoSetPeriodicity, bool NoTransparency, bool ExternalTransparency, bool MirrorEffect,
+    bool Untwist, bool DoNotFlattenTransparency, bool ShowGrid, bool ShowFrame)
+
+  # user parameters -> working variables
+  rin = InnerRadius/100;
+  rout = OuterRadius/100;
+  per = Periodicity;
+  strands = Strands;
+  cshiftx = XCenterShift/100;
+  cshifty = YCenterShift/100;
+  shiftx = (XShift*W/X)/100;
+  shifty = (YShift*H/Y)/100;
+  byAlpha = !(NoTransparency);
+  alphaInside = !(ExternalTransparency);
+  lookOut = StartingLevel;
+  showEvery = LevelFrequency;
+  twist = !(Untwist);
+
+  if (AutoSetPeriodicity) then
+    per = strands/2 * (1+sqrt(1-(log(rout/rin)/pi)^2));
+  end;
+
+  if per > 0 then
+    rot = -(pi/180) * Rotate;
+  else
+    rot = (pi/180) * Rotate;
+  end;
+
+  zm = ((Zoom+InnerRadius-1)/100);
+  eps = .01;
+
+  # viewport
+  if (twist) then
+    bx = [-rout,rout];
+    by = [-rout,rout];
+  else
+    by = [0,2.1*pi];
+    bx = [-log(rout/rin), log(rout/rin)];
+  end;
+
+  small = min(W, H);
+  mid = ri:[0.5*(bx[0]+bx[1]),0.5*(by[0]+by[1])];
+  span = xy:[bx[1]-bx[0], by[1]-by[0]];
+  aspect = W/H;
+  span[0] = span[1]*aspect;
+  bx = [mid[0]-0.5*span[0],mid[0]+0.5*span[0]];
+  z = ri:[bx[0]+(bx[1]-bx[0])*(x+W/2)/W,by[0]+(by[1]-by[0])*(y+H/2)/H];
+
+  if (twist) then
+    z0 = z;
+    z = z - ri:[shiftx,shifty];
+    z = mid+(z-mid)/zm*exp(-I*rot);
+  else
+    z0 = rin*exp(z);
+    z0 = z0*Zoom*exp(I*rot);
+  end;
+
+  if ShowBothPoles then
+    th = (pi/180)*PoleRotation;
+    u = z[0];
+    v = z[1];
+    dv = .5 * (1+ u^2 + v^2 + ((1-u^2-v^2) * cos(th)) - (2 * u * sin(th)));
+    u = u * cos(th) + (0.5*(1 - u^2 - v^2) * sin(th));
+    z = ri:[u,v];
+    z = z/dv;
+  else
+    if HyperDroste then
+      z = sin(z);
+    end;
+    if TilePoles then
+      z = z^FractalPoints;
+      z = tan(2*z);
+    end
+  end;
+
+  plat = (PoleLat*W/X)/100;
+  plon = (PoleLong*W/X)/100;
+  z = z + ri:[plat,plon];
+
+  if (twist) then
+    lz = log(z/rin);
+  else
+    lz = z;
+  end;
+
+  # the twist itself
+  alpha = atan(strands/per*log(rout/rin)/(2*pi));
+  cosa = cos(alpha);
+  beta = cosa*exp(I*alpha);
+
+  if (strands > 0) then
+    ang = 2*pi*per;
+  else
+    ang = -2*pi*per;
+  end;
+
+  if MirrorEffect then
+    ang = ang/Strands;
+  end;
+
+  z = per*lz/beta;
+  gridlz = z;
+  plainlz = lz;
+  z = rin*exp(z);
+
+  if (byAlpha && lookOut > 0) then
+    if (!alphaInside) then ratio = rout/rin*exp( I*ang); end;
+    if ( alphaInside) then ratio = rin/rout*exp(-I*ang); end;
+    z = z * (ratio^lookOut)/1;
+  end;
+
+  acc = rgba:[0,0,0,0];
+  left = 1;
+  sx = small/2*(z[0]+cshiftx);
+  sy = small/2*(z[1]+cshifty);
+  sp = xy:[sx,sy];
+
+  tap = in(sp);
+  acc = acc = acc + (tap*(alpha(tap)*left));
+  left = left*(1-alpha(tap));
+  dir = 0;
+
+  if (byAlpha) then
+    if ( alphaInside && left > eps) then
+      dir = -1;
+    end;
+    if (!alphaInside && left > eps) then
+      dir = 1;
+    end;
+  else
+    rad = sqrt(z[0]*z[0]+z[1]*z[1]);
+    if (rad < rin) then dir = -1; end;
+    if (rad > rout) then dir = 1; end;
+  end;
+
+  if (dir < 0) then
+    ratio = rout/rin*exp( I*ang);
+  end;
+
+  if (dir > 0) then
+    ratio = rin/rout*exp(-I*ang);
+  end;
+
+  if (showEvery > 1) then
+    ratio = exp(log(ratio)*showEvery);
+  end;
+
+  level = StartingLevel;
+  lastLevel = NumberOfLevels+StartingLevel-1;
+
+  while (dir != 0 && level < lastLevel) do
+    lz = z*ratio;
+    z = lz;
+    gridlz = gridlz+ri:[0,-dir*ang];
+    sx = small/2*(z[0]+cshiftx);
+    sy = small/2*(z[1]+cshifty);
+    sp = xy:[sx,sy];
+    dir = 0;
+    if (byAlpha) then
+      tap = in(sp);
+      acc = acc + (tap*(alpha(tap)*left));
+      left = left*(1-alpha(tap));
+      if ( alphaInside && left > eps) then dir = -1; end;
+      if (!alphaInside && left > eps) then dir = 1; end;
+    else
+      rad = sqrt(z[0]*z[0]+z[1]*z[1]);
+      acc = in(sp);
+      if (rad < rin) then dir = -1; end;
+      if (rad > rout) then dir = 1; end;
+    end;
+    level = level+1;
+  end;
+
+  tap = acc;
+
+  if (ShowGrid) then
+    g = xy:[(plainlz[0]+10*log(rout/rin))%log(rout/rin), (plainlz[1]+10*2*pi)%(2*pi)];
+    if (g[0] < eps || g[0] > (log(rout/rin)-eps) || g[1] < eps || g[1] > (2*pi-eps)) then
+      tap = rgba:[0,1,0,1];
+    end;
+    g = xy:[(gridlz[0]+10*log(rout/rin))%log(rout/rin), (gridlz[1]+10*2*pi)%(2*pi)];
+    if (g[0] < eps || g[0] > (log(rout/rin)-eps) || g[1] < eps || g[1] > (2*pi-eps)) then
+      tap = rgba:[0,0,1,1];
+    end;
+  end;
+
+  if (ShowFrame) then
+    g = xy:[z0[0],z0[1]];
+    if (g[0] < (aspect*rout) && g[0] > -(aspect*rout) && g[1] < rout && g[1] > -rout) then
+      ex = min((aspect*rout)-g[0], g[0]+(aspect*rout));
+      ey = min(rout-g[1], g[1]+rout);
+      if (ex < (4*eps) || ey < (4*eps)) then
+        tap = rgba:[1,1,1,1];
+      end;
+      if (ex < (2*eps) || ey < (2*eps)) then
+        tap = rgba:[0,0,0,1];
+      end;
+    else
+      tap = rgba:[0.75*red(tap),0.75*green(tap),0.75*blue(tap),1];
+    end;
+  end;
+
+  if !(DoNotFlattenTransparency) then
+    tap = rgba:[tap[0], tap[1], tap[2], 1];
+  end;
+
+  tap
+end
+"""
+
+# small filters exercising closures / filter calls (cf. the reference's tests/*.mm)
+CLOSURE_CALL = """
+filter disc (float radius)
+  grayColor(if r < radius then t else 0 end)
+end
+
+filter main (image in, float radius: 0-1.5 (1))
+  in(xy) * disc(radius, xy, 1-t)
+end
+"""
+
+CLOSURE_VALUE = """
+filter disc (float radius)
+  grayColor(if r < radius then 1 else 0 end)
+end
+
+filter main (float radius: 0-1.5 (1))
+  c = disc(radius);
+  c(xy)
+end
+"""
+
+CLOSURE_ARG = """
+filter disc (float radius)
+  grayColor(if r < radius then 0.5-t else 0 end)
+end
+
+filter both (image i1, image i2)
+  i1(xy) * i2(xy)
+end
+
+filter main (image in, float radius: 0-1.5 (1))
+  both(in, disc(radius), xy)
+end
+"""
+
+NESTED_CALLS = """
+filter dbl (image in)
+  in(xy) * 2
+end
+
+filter hlf (image in)
+  in(xy) / 2
+end
+
+filter main (image in)
+  hlf(dbl(in), xy)
+end
+"""
+
+ALL = {
+    "ident": IDENT,
+    "mandelbrot": MANDELBROT,
+    "pond": POND,
+    "gaussian_blur": GAUSSIAN_BLUR,
+    "gauss_direct": GAUSS_DIRECT,
+    "droste": DROSTE,
+    "closure_call": CLOSURE_CALL,
+    "closure_value": CLOSURE_VALUE,
+    "closure_arg": CLOSURE_ARG,
+    "nested_calls": NESTED_CALLS,
+}
+
+
+def synthetic_image(width, height, seed=1):
+    """Deterministic RGB8 test image: smooth gradients plus hashed texture, so gathers
+    see non-trivial data.  Returns uint8 [H, W, 3]."""
+    import numpy as np
+    y, x = np.mgrid[0:height, 0:width].astype(np.uint32)
+    out = np.empty((height, width, 3), np.uint8)
+    for c in range(3):
+        v = (x * np.uint32(131 + 17 * c) + y * np.uint32(71 + 29 * c) + np.uint32(seed * 977 + c * 17)) ^ ((x * y) >> np.uint32(3))
+        g = (x * np.uint32(255) // np.uint32(max(width - 1, 1)) + y * np.uint32(255) // np.uint32(max(height - 1, 1))) // np.uint32(2)
+        out[:, :, c] = ((v & np.uint32(63)) + (g * np.uint32(3)) // np.uint32(4)).astype(np.uint8)
+    return out
