@@ -81,6 +81,10 @@ int mmhip_set_int(mmhip_invocation *inv, int index, int value);
 int mmhip_set_float(mmhip_invocation *inv, int index, float value);
 int mmhip_set_bool(mmhip_invocation *inv, int index, int value);
 int mmhip_set_color(mmhip_invocation *inv, int index, float r, float g, float b, float a);
+/* curve = 1024 samples of the transfer curve over [0,1]; gradient = 1024 packed 0xRRGGBBAA colours
+   (USER_CURVE_POINTS / USER_GRADIENT_POINTS, userval.h:36-37).  Defaults: identity ramp, grey ramp. */
+int mmhip_set_curve(mmhip_invocation *inv, int index, const float *values1024);
+int mmhip_set_gradient(mmhip_invocation *inv, int index, const uint32_t *rgba1024);
 int mmhip_set_by_name(mmhip_invocation *inv, const char *name, const char *value);  /* -Dname=value */
 /* Input image from host memory: channels = 3 (RGB8, alpha forced to 255 as
    mathmap_cmdline.c:183 does) or 4 (RGBA8).  Uploaded once, stays in HBM. */
@@ -89,6 +93,8 @@ int mmhip_set_image_host(mmhip_invocation *inv, int index, const uint8_t *pixels
 int mmhip_set_image_device(mmhip_invocation *inv, int index, const void *device_rgba32, int width, int height);
 int mmhip_set_edge_colors(mmhip_invocation *inv, uint32_t color_x, uint32_t color_y);
 int mmhip_set_render_size(mmhip_invocation *inv, int render_width, int render_height);
+/* sub-pixel sampling offset of the slice (mathmap.h:219; -0.5 for the second supersampling pass) */
+int mmhip_set_sampling_offset(mmhip_invocation *inv, float offset_x, float offset_y);
 
 /* Renders rows [first_row, last_row) of region (region_x, region_y, region_w, region_h)
    at animation parameter t / frame into device memory `out_device` (row 0 of the

@@ -45,11 +45,14 @@ SYMBOLS = {
     "mmhip_set_float": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
     "mmhip_set_bool": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mmhip_set_color": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "mmhip_set_curve": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mmhip_set_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmhip_set_by_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "mmhip_set_image_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mmhip_set_image_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "mmhip_set_edge_colors": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "mmhip_set_render_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mmhip_set_sampling_offset": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
     "mmhip_render": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mmhip_render_host": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
@@ -61,6 +64,17 @@ SYMBOLS = {
     "mmhip_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mmhip_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mmhip_device_count": (C.c_int, []),
+}
+
+# reference-ABI tier (include/mathmap_hip_backend.h) and its self-test driver
+BACKEND_SYMBOLS = {
+    "gen_and_load_hip_code": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_void_p]),
+    "unload_hip_code": (None, [C.c_void_p]),
+    "mathmap_hip_set_get_pixel": (None, [C.c_void_p]),
+    "mathmap_hip_invalidate_drawable": (None, [C.c_void_p]),
+    "mmhip_selftest_abi_roundtrip": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "mmhip_selftest_error": (C.c_char_p, []),
 }
 
 _lib = None
@@ -75,7 +89,7 @@ def lib():
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C mathmap_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(BACKEND_SYMBOLS.items()):
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args

@@ -1,0 +1,522 @@
+// Reference-ABI tier: gen_and_load_hip_code / unload_hip_code and the mathfuncs_t
+// shims (init_frame, init_slice, calc_lines) a MathMap build calls instead of the cc
+// backend.  Reads the reference's structures through the layout mirrors of
+// include/mathmap_abi.h.
+//
+// Flow (reference call sites): compile_mathmap (mathmap_common.c:551-556) calls
+// gen_and_load_hip_code -> we import the main filter's IR (statement_t list) into our
+// own IR, keep it in a ModuleInfo and return `hip_mathmapinit`.  init_invocation
+// (mathmap_common.c:714-734) calls that and gets the three shims.  Per frame the host
+// calls init_frame, init_slice (no-ops here: frame constants are evaluated on the GPU
+// by the prologue kernel) and calc_lines, which renders the row band on the GPU and
+// copies it into the host buffer `q`.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <functional>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "../../include/mathmap_hip_backend.h"
+#include "passes.h"
+#include "runtime_internal.h"
+
+using namespace mm;
+
+namespace {
+
+mmabi_get_pixel_func_t g_get_pixel = nullptr;
+
+void host_error(const std::string &msg) {
+    // the reference reports backend errors through its global error_string (cc.c:653-693)
+    if (char *es = (char *)dlsym(RTLD_DEFAULT, "error_string")) {
+        strncpy(es, msg.c_str(), 1023);
+        es[1023] = 0;
+    }
+}
+
+struct Variant {
+    mmhip_filter *flt = nullptr;
+    std::map<mmabi_invocation_t *, mmhip_invocation *> invs;
+};
+
+struct DrawableCopy { int width = 0, height = 0; void *dev = nullptr; };
+
+struct ModuleInfo {
+    std::mutex mu;
+    // the imported, un-optimised IR is re-imported per variant from a serialised form:
+    // we keep one pristine filter object per option set instead
+    std::map<int, Variant> variants;           // key = option bits
+    mmabi_mathmap_t *mathmap = nullptr;
+    // everything needed to rebuild a variant
+    struct SavedFilter { Filter f; };
+    std::function<mmhip_filter *(const KernelOptions &, std::string *)> build;
+    std::map<mmabi_input_drawable_t *, DrawableCopy> drawables;
+    std::map<const float *, void *> floatmaps;
+    void *staging = nullptr;
+    size_t staging_bytes = 0;
+};
+
+std::mutex g_registry_mu;
+std::map<mmabi_input_drawable_t *, ModuleInfo *> g_drawable_owner;
+
+// ---------------------------------------------------------------------------
+// IR import (compiler-internals.h structures -> mm::FilterCode)
+// ---------------------------------------------------------------------------
+struct Importer {
+    Module &mod;
+    FilterCode &code;
+    std::map<mmabi_filter_t *, Filter *> filters;
+    std::map<mmabi_compvar_t *, CompVar *> vars;
+    std::map<mmabi_value_t *, Value *> vals;
+
+    Importer(Module &m, FilterCode &c) : mod(m), code(c) {}
+
+    static unsigned flags_of(mmabi_filter_t *f) {   // mathmap_common.c:59-72
+        bool pixel = false, stretched = false;
+        if (f->v.mathmap.decl)
+            for (mmabi_option_t *o = f->v.mathmap.decl->v.filter.options; o; o = o->next) {
+                if (!strcmp(o->name, "pixel")) pixel = true;
+                if (!strcmp(o->name, "stretched")) stretched = true;
+            }
+        unsigned fl = 0;
+        if (!pixel) { fl |= IMAGE_FLAG_UNIT; if (!stretched) fl |= IMAGE_FLAG_SQUARE; }
+        return fl;
+    }
+
+    Filter *filter(mmabi_filter_t *rf) {
+        auto it = filters.find(rf);
+        if (it != filters.end()) return it->second;
+        Filter *f = nullptr;
+        if (rf->kind == MMABI_FILTER_NATIVE) {
+            for (auto &own : mod.filters)
+                if (own->kind == Filter::Native && own->native_func == rf->v.native.func_name) f = own.get();
+            if (!f) throw CompileError(std::string("unknown native filter ") + rf->v.native.func_name);
+        } else {
+            mod.filters.emplace_back(new Filter());
+            f = mod.filters.back().get();
+            f->kind = Filter::MathMap;
+            f->name = rf->name;
+            f->flags = flags_of(rf);
+            for (mmabi_userval_info_t *u = rf->userval_infos; u; u = u->next) {
+                UservalInfo ui;
+                ui.name = u->name;
+                ui.index = u->index;
+                switch (u->type) {
+                    case MMABI_USERVAL_INT_CONST:
+                        ui.kind = UvKind::Int; ui.imin = u->v.int_const.min; ui.imax = u->v.int_const.max;
+                        ui.idef = u->v.int_const.default_value; break;
+                    case MMABI_USERVAL_FLOAT_CONST:
+                        ui.kind = UvKind::Float; ui.fmin = u->v.float_const.min; ui.fmax = u->v.float_const.max;
+                        ui.fdef = u->v.float_const.default_value; break;
+                    case MMABI_USERVAL_BOOL_CONST: ui.kind = UvKind::Bool; ui.bdef = u->v.bool_const.default_value != 0; break;
+                    case MMABI_USERVAL_COLOR: ui.kind = UvKind::Color; break;
+                    case MMABI_USERVAL_CURVE: ui.kind = UvKind::Curve; break;
+                    case MMABI_USERVAL_GRADIENT: ui.kind = UvKind::Gradient; break;
+                    case MMABI_USERVAL_IMAGE: ui.kind = UvKind::Image; ui.image_flags = u->v.image.flags; break;
+                    default: throw CompileError("unknown user value type in filter " + f->name);
+                }
+                f->uservals.push_back(ui);
+            }
+            // the reference keeps the list in registration order with ascending indices
+            std::sort(f->uservals.begin(), f->uservals.end(),
+                      [](const UservalInfo &a, const UservalInfo &b) { return a.index < b.index; });
+        }
+        filters[rf] = f;
+        return f;
+    }
+
+    CompVar *var(mmabi_compvar_t *rv) {
+        auto it = vars.find(rv);
+        if (it != vars.end()) return it->second;
+        std::string name = rv->var ? rv->var->name : "";
+        CompVar *v = code.new_var((Ty)rv->type, name, rv->n);
+        vars[rv] = v;
+        return v;
+    }
+
+    Value *value(mmabi_value_t *rv) {
+        auto it = vals.find(rv);
+        if (it != vals.end()) return it->second;
+        CompVar *cv = var(rv->compvar);
+        Value *v;
+        if (rv->index < 0) v = cv->current;   // the uninitialised value every compvar starts with
+        else {
+            v = code.new_value(cv);
+            v->index = rv->index;
+        }
+        vals[rv] = v;
+        return v;
+    }
+
+    Primary primary(const mmabi_primary_t &p) {
+        if (p.kind == MMABI_PRIMARY_VALUE) return Primary::V(value(p.v.value));
+        Primary q;
+        switch (p.const_type) {
+            case MMABI_TYPE_INT: return Primary::I(p.v.constant.int_value);
+            case MMABI_TYPE_FLOAT: return Primary::F(p.v.constant.float_value);
+            case MMABI_TYPE_COMPLEX:
+                q.kind = Primary::ComplexConst; q.f = p.v.constant.complex_value[0]; q.f2 = p.v.constant.complex_value[1];
+                return q;
+            case MMABI_TYPE_COLOR: q.kind = Primary::ColorConst; q.color = p.v.constant.color_value; return q;
+            default: throw CompileError("constant of a non-scalar type in the IR");
+        }
+    }
+
+    Rhs rhs(mmabi_rhs_t *r) {
+        Rhs out;
+        switch (r->kind) {
+            case MMABI_RHS_PRIMARY: return Rhs::P(primary(r->v.primary));
+            case MMABI_RHS_INTERNAL: return Rhs::Int(r->v.internal->name);
+            case MMABI_RHS_OP: {
+                const OpInfo *op = op_by_cname(r->v.op.op->name, r->v.op.op->num_args);
+                if (!op) throw CompileError(std::string("unknown IR operator ") + r->v.op.op->name);
+                std::vector<Primary> args;
+                for (int i = 0; i < op->nargs; ++i) args.push_back(primary(r->v.op.args[i]));
+                return Rhs::O(op, args);
+            }
+            case MMABI_RHS_CLOSURE: {
+                out.kind = Rhs::Closure;
+                out.filter = filter(r->v.closure.filter);
+                for (int i = 0; i < r->v.closure.filter->num_uservals; ++i) out.args.push_back(primary(r->v.closure.args[i]));
+                return out;
+            }
+            case MMABI_RHS_TUPLE:
+                out.kind = Rhs::Tuple;
+                for (int i = 0; i < r->v.tuple.length; ++i) out.args.push_back(primary(r->v.tuple.args[i]));
+                return out;
+            case MMABI_RHS_FILTER:
+                throw CompileError(std::string("filter `") + r->v.filter.filter->name +
+                                   "' is called without being inlined (recursion); not supported by the HIP backend yet");
+            default: throw CompileError("tree vectors are not supported by the HIP backend yet");
+        }
+    }
+
+    void phis(mmabi_statement_t *s, Block &out, Stmt *parent) {
+        for (; s; s = s->next) {
+            if (s->kind != MMABI_STMT_PHI_ASSIGN) continue;
+            Stmt *p = code.new_stmt(Stmt::Phi);
+            p->lhs = value(s->v.assign.lhs);
+            p->lhs->def = p;
+            p->rhs = rhs(s->v.assign.rhs);
+            p->rhs2 = rhs(s->v.assign.rhs2);
+            p->parent = parent;
+            out.push_back(p);
+        }
+    }
+
+    void block(mmabi_statement_t *s, Block &out, Stmt *parent) {
+        for (; s; s = s->next) {
+            switch (s->kind) {
+                case MMABI_STMT_NIL: break;
+                case MMABI_STMT_ASSIGN: {
+                    Stmt *a = code.new_stmt(Stmt::Assign);
+                    a->lhs = value(s->v.assign.lhs);
+                    a->lhs->def = a;
+                    a->rhs = rhs(s->v.assign.rhs);
+                    a->parent = parent;
+                    out.push_back(a);
+                    break;
+                }
+                case MMABI_STMT_IF_COND: {
+                    Stmt *i = code.new_stmt(Stmt::If);
+                    i->cond = rhs(s->v.if_cond.condition);
+                    i->parent = parent;
+                    block(s->v.if_cond.consequent, i->then_, i);
+                    block(s->v.if_cond.alternative, i->else_, i);
+                    phis(s->v.if_cond.exit, i->phis, i);
+                    out.push_back(i);
+                    break;
+                }
+                case MMABI_STMT_WHILE_LOOP: {
+                    Stmt *w = code.new_stmt(Stmt::While);
+                    w->parent = parent;
+                    phis(s->v.while_loop.entry, w->phis, w);
+                    w->cond = rhs(s->v.while_loop.invariant);
+                    block(s->v.while_loop.body, w->body, w);
+                    out.push_back(w);
+                    break;
+                }
+                default: throw CompileError("phi statement outside a phi list");
+            }
+        }
+    }
+
+    // compiler.c:4692-4697: the filter result is `dummy = OUTPUT_TUPLE(tuple)` where
+    // `tuple` was assigned RHS_TUPLE(r,g,b,a)
+    void find_result() {
+        Stmt *outp = nullptr;
+        for (Stmt *s : code.body)
+            if (s->kind == Stmt::Assign && s->rhs.kind == Rhs::Op && !strcmp(s->rhs.op->cname, "OUTPUT_TUPLE")) outp = s;
+        if (!outp || outp->rhs.args[0].kind != Primary::Val) throw CompileError("IR has no OUTPUT_TUPLE statement");
+        Stmt *def = outp->rhs.args[0].value->def;
+        if (!def || def->rhs.kind != Rhs::Tuple || def->rhs.args.size() != 4)
+            throw CompileError("OUTPUT_TUPLE argument is not a 4-tuple");
+        Block extra;
+        for (int i = 0; i < 4; ++i) {
+            const Primary &p = def->rhs.args[i];
+            if (p.kind == Primary::Val) code.result[i] = p.value;
+            else {
+                CompVar *t = code.new_var(p.type());
+                Stmt *a = code.new_stmt(Stmt::Assign);
+                a->lhs = code.new_value(t);
+                a->lhs->def = a;
+                a->rhs = Rhs::P(p);
+                extra.push_back(a);
+                code.result[i] = a->lhs;
+            }
+        }
+        // drop the OUTPUT_TUPLE pseudo statement; the backends pack the result themselves
+        Block kept;
+        for (Stmt *s : code.body)
+            if (s != outp) kept.push_back(s);
+        for (Stmt *s : extra) kept.push_back(s);
+        code.body.swap(kept);
+    }
+};
+
+int option_key(const KernelOptions &k) {
+    return (k.intersample & 1) | ((k.supersampling & 1) << 1) | ((k.edge_x & 3) << 2) | ((k.edge_y & 3) << 4);
+}
+
+Variant *get_variant(ModuleInfo *mi, mmabi_invocation_t *inv) {
+    KernelOptions ko;
+    ko.intersample = inv->antialiasing ? 1 : 0;       // invocation_set_antialiasing, mathmap_common.c:736-743
+    ko.supersampling = inv->supersampling ? 1 : 0;
+    ko.edge_x = inv->edge_behaviour_x;                // EDGE_BEHAVIOUR_* (mathmap.h:134-138) = our numbering + 1
+    ko.edge_y = inv->edge_behaviour_y;
+    // reference: COLOR=1 WRAP=2 REFLECT=3 ROTATE=4
+    ko.edge_x = ko.edge_x >= 1 && ko.edge_x <= 4 ? ko.edge_x - 1 : 0;
+    ko.edge_y = ko.edge_y >= 1 && ko.edge_y <= 4 ? ko.edge_y - 1 : 0;
+    Variant &v = mi->variants[option_key(ko)];
+    if (!v.flt) {
+        std::string err;
+        v.flt = mi->build(ko, &err);
+        if (!v.flt) { host_error("HIP backend: " + err); return nullptr; }
+    }
+    return &v;
+}
+
+// ---------------------------------------------------------------------------
+// mathfuncs shims
+// ---------------------------------------------------------------------------
+void hip_init_frame(mmabi_frame_t *, mmabi_image_t *) {}
+void hip_init_slice(mmabi_slice_t *, mmabi_image_t *) {}
+
+bool upload_drawable(ModuleInfo *mi, mmabi_invocation_t *inv, mmabi_input_drawable_t *d, DrawableCopy *out) {
+    auto it = mi->drawables.find(d);
+    if (it != mi->drawables.end() && it->second.width == d->image.pixel_width && it->second.height == d->image.pixel_height) {
+        *out = it->second;
+        return true;
+    }
+    mmabi_get_pixel_func_t gp = g_get_pixel;
+    if (!gp) gp = (mmabi_get_pixel_func_t)dlsym(RTLD_DEFAULT, "mathmap_get_pixel");
+    if (!gp) { host_error("HIP backend: host symbol mathmap_get_pixel not found"); return false; }
+    int w = d->image.pixel_width, h = d->image.pixel_height;
+    std::vector<uint32_t> px((size_t)w * h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) px[(size_t)y * w + x] = gp(inv, d, 0, x, y);
+    DrawableCopy c;
+    c.width = w;
+    c.height = h;
+    if (hipMalloc(&c.dev, px.size() * 4) != hipSuccess) { host_error("HIP backend: out of device memory"); return false; }
+    (void)hipMemcpy(c.dev, px.data(), px.size() * 4, hipMemcpyHostToDevice);
+    if (it != mi->drawables.end() && it->second.dev) (void)hipFree(it->second.dev);
+    mi->drawables[d] = c;
+    {
+        std::lock_guard<std::mutex> g(g_registry_mu);
+        g_drawable_owner[d] = mi;
+    }
+    *out = c;
+    return true;
+}
+
+void hip_calc_lines(mmabi_slice_t *slice, mmabi_image_t *closure, int first_row, int last_row, void *q, int floatmap) {
+    mmabi_frame_t *frame = slice->frame;
+    mmabi_invocation_t *inv = frame->invocation;
+    ModuleInfo *mi = (ModuleInfo *)inv->mathmap->module_info;
+    std::lock_guard<std::mutex> guard(mi->mu);   // calc_lines may be entered from several row threads
+    Variant *v = get_variant(mi, inv);
+    if (!v) return;
+    mmhip_invocation *&hi = v->invs[inv];
+    if (!hi) {
+        hi = mmhip_invoke(v->flt, inv->img_width, inv->img_height);
+        if (!hi) { host_error(std::string("HIP backend: ") + mmhip_last_error()); return; }
+    }
+    mmhip_set_render_size(hi, frame->frame_render_width, frame->frame_render_height);
+    mmhip_set_sampling_offset(hi, slice->sampling_offset_x, slice->sampling_offset_y);
+    mmhip_set_edge_colors(hi, inv->edge_color_x, inv->edge_color_y);
+    // user values come from the closure's argument block (new_template.c.in:234)
+    const auto &uvs = v->flt->module.main->uservals;
+    for (const UservalInfo &u : uvs) {
+        const mmabi_userval_t &a = closure->v.closure.args[u.index];
+        switch (u.kind) {
+            case UvKind::Int: mmhip_set_int(hi, u.index, a.v.int_const); break;
+            case UvKind::Float: mmhip_set_float(hi, u.index, a.v.float_const); break;
+            case UvKind::Bool: mmhip_set_bool(hi, u.index, a.v.bool_const); break;
+            case UvKind::Color:
+                hi->uv[u.index].c = a.v.color.value;
+                hi->tables_dirty = true;
+                break;
+            case UvKind::Image: {
+                mmabi_image_t *img = a.v.image;
+                while (img && img->type == MMABI_IMAGE_RESIZE) img = img->v.resize.original;
+                if (img && img->type == MMABI_IMAGE_DRAWABLE && img->v.drawable) {
+                    DrawableCopy c;
+                    if (!upload_drawable(mi, inv, img->v.drawable, &c)) return;
+                    int slot = hi->image_slot_of_uv[u.index];
+                    if (hi->images[slot].data != c.dev) mmhip_set_image_device(hi, u.index, c.dev, c.width, c.height);
+                    // the host may have set its own scale/middle (userval.c:262-280); keep them
+                    hi->images[slot].scale_x = img->v.drawable->scale_x;
+                    hi->images[slot].scale_y = img->v.drawable->scale_y;
+                    hi->images[slot].middle_x = img->v.drawable->middle_x;
+                    hi->images[slot].middle_y = img->v.drawable->middle_y;
+                } else if (img && img->type == MMABI_IMAGE_CLOSURE) {
+                    host_error("HIP backend: closure images as top-level arguments are not supported yet");
+                    return;
+                }
+                break;
+            }
+            default: break;   // curves / gradients: LUT upload is not wired up yet
+        }
+    }
+    // new_template.c.in:238-239
+    if (first_row < 0) first_row = 0;
+    if (last_row > slice->region_y + slice->region_height) last_row = slice->region_y + slice->region_height;
+    int rows = last_row - first_row;
+    if (rows <= 0) return;
+    int bpp = inv->output_bpp;
+    size_t dev_stride = floatmap ? (size_t)frame->frame_render_width * 16 : (size_t)slice->region_width * bpp;
+    size_t need = dev_stride * rows;
+    if (need > mi->staging_bytes) {
+        if (mi->staging) (void)hipFree(mi->staging);
+        mi->staging = nullptr;
+        mi->staging_bytes = 0;
+        if (hipMalloc(&mi->staging, need) != hipSuccess) { host_error("HIP backend: out of device memory"); return; }
+        mi->staging_bytes = need;
+    }
+    int rc = mmhip_render(hi, frame->current_frame, frame->current_t, slice->region_x, slice->region_y, slice->region_width,
+                          slice->region_height, first_row, last_row, mi->staging, (int)dev_stride, bpp, floatmap, nullptr);
+    if (rc != 0) { host_error(std::string("HIP backend: ") + mmhip_last_error()); return; }
+    mmhip_sync(hi);
+    if (floatmap) {
+        (void)hipMemcpy(q, mi->staging, need, hipMemcpyDeviceToHost);
+    } else {
+        (void)hipMemcpy2D(q, (size_t)inv->row_stride, mi->staging, dev_stride, dev_stride, (size_t)rows, hipMemcpyDeviceToHost);
+    }
+    // new_template.c.in:307-308
+    if (!inv->supersampling && inv->rows_finished)
+        for (int r = first_row - slice->region_y; r < last_row - slice->region_y; ++r) inv->rows_finished[r] = 1;
+}
+
+mmabi_mathfuncs_t hip_mathmapinit(mmabi_invocation_t *) {
+    mmabi_mathfuncs_t f;
+    memset(&f, 0, sizeof f);
+    f.init_frame = hip_init_frame;
+    f.init_slice = hip_init_slice;
+    f.calc_lines = hip_calc_lines;
+    return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_info, char *, char *,
+                                       mmabi_filter_code_t **filter_codes) {
+    int index = 0;
+    mmabi_filter_code_t *main_code = nullptr;
+    for (mmabi_filter_t *f = mathmap->filters; f; f = f->next, ++index)
+        if (f == mathmap->main_filter) main_code = filter_codes[index];
+    if (!main_code) { host_error("HIP backend: main filter has no code"); return nullptr; }
+
+    // Import once into a pristine filter object; per option set we re-import from the
+    // reference structures only now (they are freed right after this call,
+    // mathmap_common.c:558), so keep a serialised pristine copy: the IR JSON is not
+    // re-parsable here, therefore all option variants are built eagerly on demand from
+    // a deep copy made by importing again into separate objects up front.
+    std::unique_ptr<ModuleInfo> mi(new ModuleInfo());
+    mi->mathmap = mathmap;
+    // Pre-build the 2 sampling variants x default edge mode now; other edge modes are
+    // rare (GIMP dialog only) and are imported eagerly too to stay independent of the
+    // freed IR.
+    std::vector<KernelOptions> wanted;
+    for (int inter = 0; inter < 2; ++inter)
+        for (int ss = 0; ss < 2; ++ss)
+            for (int ex = 0; ex < 4; ++ex)
+                for (int ey = 0; ey < 4; ++ey) {
+                    KernelOptions k;
+                    k.intersample = inter; k.supersampling = ss; k.edge_x = ex; k.edge_y = ey;
+                    wanted.push_back(k);
+                }
+    // importing is cheap; hiprtc compilation happens lazily on first use of a variant
+    std::map<int, mmhip_filter *> prebuilt;
+    std::string first_err;
+    for (const KernelOptions &k : wanted) {
+        mmhip_filter *f = mmhip_filter_new_empty();
+        try {
+            f->code.reset(new FilterCode());
+            Importer imp(f->module, *f->code);
+            f->module.main = imp.filter(mathmap->main_filter);
+            imp.block(main_code->first_stmt, f->code->body, nullptr);
+            imp.find_result();
+            std::string err;
+            if (!mmhip_filter_finalize(f, k, &err)) throw CompileError(err);
+        } catch (const std::exception &e) {
+            first_err = e.what();
+            mmhip_filter_free(f);
+            f = nullptr;
+        }
+        if (!f) break;
+        prebuilt[option_key(k)] = f;
+    }
+    if (!first_err.empty()) {
+        for (auto &p : prebuilt) mmhip_filter_free(p.second);
+        host_error("HIP backend: " + first_err);
+        return nullptr;
+    }
+    for (auto &p : prebuilt) mi->variants[p.first].flt = p.second;
+    mi->build = [](const KernelOptions &, std::string *err) -> mmhip_filter * {
+        *err = "kernel variant was not prepared";
+        return nullptr;
+    };
+    *module_info = mi.release();
+    return hip_mathmapinit;
+}
+
+void unload_hip_code(void *module_info) {
+    ModuleInfo *mi = (ModuleInfo *)module_info;
+    if (!mi) return;
+    {
+        std::lock_guard<std::mutex> g(g_registry_mu);
+        for (auto it = g_drawable_owner.begin(); it != g_drawable_owner.end();)
+            it = it->second == mi ? g_drawable_owner.erase(it) : std::next(it);
+    }
+    for (auto &v : mi->variants) {
+        for (auto &i : v.second.invs) mmhip_invocation_free(i.second);
+        mmhip_filter_free(v.second.flt);
+    }
+    for (auto &d : mi->drawables) if (d.second.dev) (void)hipFree(d.second.dev);
+    if (mi->staging) (void)hipFree(mi->staging);
+    delete mi;
+}
+
+void mathmap_hip_set_get_pixel(mmabi_get_pixel_func_t fn) { g_get_pixel = fn; }
+
+void mathmap_hip_invalidate_drawable(mmabi_input_drawable_t *drawable) {
+    std::lock_guard<std::mutex> g(g_registry_mu);
+    auto it = g_drawable_owner.find(drawable);
+    if (it == g_drawable_owner.end()) return;
+    ModuleInfo *mi = it->second;
+    std::lock_guard<std::mutex> g2(mi->mu);
+    auto d = mi->drawables.find(drawable);
+    if (d != mi->drawables.end()) {
+        if (d->second.dev) (void)hipFree(d->second.dev);
+        mi->drawables.erase(d);
+    }
+    g_drawable_owner.erase(it);
+}
+
+}  // extern "C"

@@ -26,6 +26,7 @@
 #include "mm_host_abi.h"
 #include "native_filters.h"
 #include "passes.h"
+#include "runtime_internal.h"
 
 using namespace mm;
 
@@ -52,43 +53,6 @@ std::string cache_dir() {
 }
 
 }  // namespace
-
-struct mmhip_filter {
-    Module module;
-    std::unique_ptr<FilterCode> code;
-    KernelOptions kopt;
-    KernelSource ks;
-    std::string ir_json;
-    std::vector<char> code_object;
-    hipModule_t mod = nullptr;
-    hipFunction_t f_pro = nullptr, f_pix = nullptr;
-    bool loaded = false;
-    double jit_seconds = 0;
-};
-
-struct mmhip_invocation {
-    mmhip_filter *f = nullptr;
-    int img_w = 0, img_h = 0, render_w = 0, render_h = 0;
-    std::vector<HUserval> uv;
-    std::vector<HImageDesc> images;
-    std::vector<int> image_slot_of_uv;     // userval index -> image table slot (or -1)
-    int native_slot_base = 0;
-    HUserval *d_uv = nullptr;
-    HImageDesc *d_images = nullptr;
-    bool tables_dirty = true;
-    std::vector<void *> owned;             // device buffers we allocated for input images
-    std::vector<void *> native_maps;       // float4 maps produced by native filters
-    std::vector<HNativeRec> native_memo;   // args of the call that produced native_maps[k]
-    std::vector<unsigned long long> native_memo_gen;
-    unsigned long long input_generation = 1;
-    char *d_xy = nullptr;
-    hipStream_t stream = nullptr;
-    uint32_t edge_color_x = 0, edge_color_y = 0;
-    bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
-    NativeWorkspace ws;
-};
 
 extern "C" {
 
@@ -129,6 +93,28 @@ mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts) {
     }
     return f.release();
 }
+
+}  // extern "C"
+
+mmhip_filter *mmhip_filter_new_empty() { return new mmhip_filter(); }
+
+// `f->module.main` and `f->code` have been filled in by the caller (the ABI importer).
+bool mmhip_filter_finalize(mmhip_filter *f, const KernelOptions &ko, std::string *err) {
+    try {
+        f->code->filter = f->module.main;
+        optimize(*f->code);
+        analyze_frame_constants(*f->code);
+        f->kopt = ko;
+        f->ir_json = dump_ir(*f->code);
+        f->ks = generate_hip(*f->code, ko);
+    } catch (const std::exception &e) {
+        *err = e.what();
+        return false;
+    }
+    return true;
+}
+
+extern "C" {
 
 void mmhip_filter_free(mmhip_filter *f) {
     if (!f) return;
@@ -229,8 +215,20 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
             case UvKind::Float: v.f = u.fdef; break;
             case UvKind::Bool: v.i = u.bdef ? 1 : 0; break;
             case UvKind::Color: v.c = 0x000000ffu; break;   // opaque black
-            case UvKind::Curve:
-            case UvKind::Gradient: v.i = 0; break;
+            case UvKind::Curve: {   // default curve: identity ramp (userval.c:282-311)
+                v.i = (int)(inv->curves.size() / 1024);
+                for (int i = 0; i < 1024; ++i) inv->curves.push_back((float)i / (float)(1024 - 1));
+                break;
+            }
+            case UvKind::Gradient: {   // default gradient: opaque grey ramp (mathmap.c:356-361)
+                v.i = (int)(inv->gradients.size() / 1024);
+                for (int i = 0; i < 1024; ++i) {
+                    float g = (float)i / (float)(1024 - 1);
+                    uint32_t q = (uint32_t)(int)(g * 255.0) & 0xff;
+                    inv->gradients.push_back((q << 24) | (q << 16) | (q << 8) | 255u);
+                }
+                break;
+            }
             case UvKind::Image: {
                 int slot = (int)inv->images.size();
                 inv->image_slot_of_uv[u.index] = slot;
@@ -261,6 +259,8 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
     if ((e = hipMalloc((void **)&inv->d_uv, inv->uv.size() * sizeof(HUserval))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&inv->d_images, inv->images.size() * sizeof(HImageDesc))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&inv->d_xy, f->ks.xy_bytes)) != hipSuccess) return bail("hipMalloc", e);
+    if (!inv->curves.empty() && (e = hipMalloc((void **)&inv->d_curves, inv->curves.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
+    if (!inv->gradients.empty() && (e = hipMalloc((void **)&inv->d_gradients, inv->gradients.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(inv->d_xy, 0, f->ks.xy_bytes)) != hipSuccess) return bail("hipMemset", e);
     return inv.release();
 }
@@ -274,6 +274,8 @@ void mmhip_invocation_free(mmhip_invocation *inv) {
     if (inv->d_uv) (void)hipFree(inv->d_uv);
     if (inv->d_images) (void)hipFree(inv->d_images);
     if (inv->d_xy) (void)hipFree(inv->d_xy);
+    if (inv->d_curves) (void)hipFree(inv->d_curves);
+    if (inv->d_gradients) (void)hipFree(inv->d_gradients);
     if (inv->ev0) (void)hipEventDestroy(inv->ev0);
     if (inv->ev1) (void)hipEventDestroy(inv->ev1);
     if (inv->stream) (void)hipStreamDestroy(inv->stream);
@@ -374,6 +376,20 @@ int mmhip_set_image_host(mmhip_invocation *inv, int index, const uint8_t *pixels
     return mmhip_set_image_device(inv, index, d, width, height);
 }
 
+int mmhip_set_curve(mmhip_invocation *inv, int index, const float *values1024) {
+    if (!uv_info(inv, index, UvKind::Curve)) return -1;
+    memcpy(&inv->curves[(size_t)inv->uv[index].i * 1024], values1024, 1024 * sizeof(float));
+    inv->tables_dirty = true;
+    return 0;
+}
+
+int mmhip_set_gradient(mmhip_invocation *inv, int index, const uint32_t *rgba1024) {
+    if (!uv_info(inv, index, UvKind::Gradient)) return -1;
+    memcpy(&inv->gradients[(size_t)inv->uv[index].i * 1024], rgba1024, 1024 * sizeof(uint32_t));
+    inv->tables_dirty = true;
+    return 0;
+}
+
 int mmhip_set_edge_colors(mmhip_invocation *inv, uint32_t cx, uint32_t cy) {
     inv->edge_color_x = cx;
     inv->edge_color_y = cy;
@@ -383,6 +399,12 @@ int mmhip_set_edge_colors(mmhip_invocation *inv, uint32_t cx, uint32_t cy) {
 int mmhip_set_render_size(mmhip_invocation *inv, int rw, int rh) {
     inv->render_w = rw;
     inv->render_h = rh;
+    return 0;
+}
+
+int mmhip_set_sampling_offset(mmhip_invocation *inv, float ox, float oy) {
+    inv->sampling_offset_x = ox;
+    inv->sampling_offset_y = oy;
     return 0;
 }
 
@@ -409,6 +431,8 @@ static int upload_tables(mmhip_invocation *inv, hipStream_t s) {
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpy(inv->d_uv, inv->uv.data(), inv->uv.size() * sizeof(HUserval), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(inv->d_images, inv->images.data(), inv->images.size() * sizeof(HImageDesc), hipMemcpyHostToDevice));
+    if (inv->d_curves) HIP_TRY(hipMemcpy(inv->d_curves, inv->curves.data(), inv->curves.size() * 4, hipMemcpyHostToDevice));
+    if (inv->d_gradients) HIP_TRY(hipMemcpy(inv->d_gradients, inv->gradients.data(), inv->gradients.size() * 4, hipMemcpyHostToDevice));
     inv->tables_dirty = false;
     return 0;
 }
@@ -480,8 +504,8 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     a.region_y = region_y;
     a.region_width = region_w;
     a.region_height = region_h;
-    a.sampling_offset_x = 0.f;
-    a.sampling_offset_y = 0.f;
+    a.sampling_offset_x = inv->sampling_offset_x;
+    a.sampling_offset_y = inv->sampling_offset_y;
     a.first_row = first_row;
     a.num_rows = last_row - first_row;
     a.output_bpp = bpp;
@@ -491,8 +515,8 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     a.edge_color_y = inv->edge_color_y;
     a.uservals = inv->d_uv;
     a.images = inv->d_images;
-    a.curves = nullptr;
-    a.gradients = nullptr;
+    a.curves = inv->d_curves;
+    a.gradients = inv->d_gradients;
     a.out = out_device;
     a.native_slot_base = inv->native_slot_base;
 

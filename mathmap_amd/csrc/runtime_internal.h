@@ -1,0 +1,61 @@
+// Internal definitions shared by runtime.cpp and abi_backend.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mmhip.h"
+#include "front.h"
+#include "hipgen.h"
+#include "mm_host_abi.h"
+#include "native_filters.h"
+
+struct mmhip_filter {
+    mm::Module module;
+    std::unique_ptr<mm::FilterCode> code;
+    mm::KernelOptions kopt;
+    mm::KernelSource ks;
+    std::string ir_json;
+    std::vector<char> code_object;
+    hipModule_t mod = nullptr;
+    hipFunction_t f_pro = nullptr, f_pix = nullptr;
+    bool loaded = false;
+    double jit_seconds = 0;
+};
+
+struct mmhip_invocation {
+    mmhip_filter *f = nullptr;
+    int img_w = 0, img_h = 0, render_w = 0, render_h = 0;
+    std::vector<mm::HUserval> uv;
+    std::vector<mm::HImageDesc> images;
+    std::vector<int> image_slot_of_uv;     // userval index -> image table slot (or -1)
+    std::vector<float> curves;             // [n_curves][1024] (userval.h:37, userval.c:282-311)
+    std::vector<uint32_t> gradients;       // [n_gradients][1024] packed 0xRRGGBBAA
+    float *d_curves = nullptr;
+    uint32_t *d_gradients = nullptr;
+    int native_slot_base = 0;
+    mm::HUserval *d_uv = nullptr;
+    mm::HImageDesc *d_images = nullptr;
+    bool tables_dirty = true;
+    std::vector<void *> owned;             // device buffers we allocated for input images
+    std::vector<void *> native_maps;       // float4 maps produced by native filters
+    std::vector<mm::HNativeRec> native_memo;   // args of the call that produced native_maps[k]
+    std::vector<unsigned long long> native_memo_gen;
+    unsigned long long input_generation = 1;
+    char *d_xy = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t edge_color_x = 0, edge_color_y = 0;
+    float sampling_offset_x = 0.f, sampling_offset_y = 0.f;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    mm::NativeWorkspace ws;
+};
+
+
+// Two-step construction from already lowered IR (used by the reference-ABI importer):
+// create, fill f->module (filters, main) and f->code, then finalize (passes + codegen).
+mmhip_filter *mmhip_filter_new_empty();
+bool mmhip_filter_finalize(mmhip_filter *f, const mm::KernelOptions &ko, std::string *err);

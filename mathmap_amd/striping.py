@@ -1,0 +1,48 @@
+"""Row-stripe decomposition of a frame across GPUs (one process per GPU).
+
+The reference parallelises a render by contiguous row bands on threads
+(call_invocation_parallel, mathmap_common.c:991-1003); the same band formula is used
+here across ranks.  Pixels are independent, so the data path needs no collective:
+every rank holds a replica of the (small) input image and renders rows
+[H*g/G, H*(g+1)/G) of the output into its own HBM.  Only gathering the finished stripes
+on one rank (for writing a file) communicates, and only the Gaussian blur's vertical
+pass needs halo rows from its neighbours.
+"""
+
+
+def stripe_rows(height, rank, world):
+    """Rows [lo, hi) of rank `rank` out of `world`: the reference's band formula."""
+    lo = height * rank // world
+    hi = height * (rank + 1) // world
+    return lo, hi
+
+
+def render_stripe(inv, out_ptr, rank, world, t=0.0, frame=0, stream=0, bpp=4):
+    """Renders this rank's stripe of the frame into device memory at out_ptr (first row of
+    the stripe).  Coordinates are computed from absolute rows, so the union of all ranks'
+    stripes is bit-identical to a single-GPU render."""
+    lo, hi = stripe_rows(inv.height, rank, world)
+    inv.render_rows(out_ptr, lo, hi, t=t, frame=frame, bpp=bpp, stream=stream)
+    return lo, hi
+
+
+def gather_stripes(local_stripe, height, rank, world, group=None):
+    """Collects the stripes on rank 0 as one [H, W, C] tensor (torch.distributed gather; RCCL
+    over xGMI on GPUs, gloo on CPU tensors).  Stripe heights may differ by one row."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local_stripe
+    w, c = local_stripe.shape[1], local_stripe.shape[2]
+    max_rows = max(stripe_rows(height, r, world)[1] - stripe_rows(height, r, world)[0] for r in range(world))
+    padded = torch.zeros((max_rows, w, c), dtype=local_stripe.dtype, device=local_stripe.device)
+    padded[: local_stripe.shape[0]] = local_stripe
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    parts = []
+    for r in range(world):
+        lo, hi = stripe_rows(height, r, world)
+        parts.append(bufs[r][: hi - lo])
+    return torch.cat(parts, dim=0)

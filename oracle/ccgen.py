@@ -376,6 +376,7 @@ class CpuFilter:
         uv = (_Userval * n_uv)()
         descs = []
         keep = []
+        curves, grads = [], []
         for u in infos:
             k, i, name = u["kind"], u["index"], u["name"]
             if k == 0:
@@ -402,6 +403,17 @@ class CpuFilter:
                     d.kind = 2
                 uv[i].image = len(descs)
                 descs.append(d)
+            elif k == 4:   # curve: default identity ramp (userval.c:282-311)
+                uv[i].i = len(curves)
+                curves.append(uservals.get(name, np.arange(1024, dtype=np.float32) / np.float32(1023)))
+            elif k == 5:   # gradient: default opaque grey ramp (mathmap.c:356-361)
+                uv[i].i = len(grads)
+                if name in uservals:
+                    grads.append(np.asarray(uservals[name], dtype=np.uint32))
+                else:
+                    v = np.arange(1024, dtype=np.float32) / np.float32(1023)
+                    q = (v.astype(np.float64) * 255.0).astype(np.uint32) & 0xff
+                    grads.append((q << 24) | (q << 16) | (q << 8) | np.uint32(255))
             else:
                 uv[i].i = 0
         nbase = len(descs)
@@ -426,6 +438,9 @@ class CpuFilter:
         a.edge_behaviour_x, a.edge_behaviour_y = edge
         a.edge_color_x, a.edge_color_y = edge_colors
         a.uservals, a.images, a.num_images, a.native_slot_base, a.memo = uv, dtab, len(descs), nbase, memo
+        ctab = np.ascontiguousarray(np.concatenate(curves).astype(np.float32)) if curves else np.zeros(1, np.float32)
+        gtab = np.ascontiguousarray(np.concatenate(grads).astype(np.uint32)) if grads else np.zeros(1, np.uint32)
+        a.curves, a.gradients = ctab.ctypes.data, gtab.ctypes.data
         out = np.zeros((height, width, 4), np.float32) if floatmap else np.zeros((height, width, bpp), np.uint8)
         xy = C.create_string_buffer(max(self.lib.mmo_xy_size(), 16))
         r0, r1 = rows if rows is not None else (0, height)

@@ -1,0 +1,240 @@
+"""CPU-only tests (`-m "not gpu"`): the oracle against the reference's golden PNGs, the
+host logic (front-end, IR, code generator, offline hiprtc compile) and the C-ABI
+library's exported surface.  No compute call needs a GPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mathmap_amd as mm
+from mathmap_amd import workloads as W
+from mathmap_amd._lib import BACKEND_SYMBOLS, LIB_PATH, SYMBOLS, lib
+from oracle.ccgen import CpuFilter
+from tests.conftest import REFERENCE, ROOT, load_png_rgb
+
+
+def oracle_render(src, uv=None, image=None, w=256, h=256, t=0.0, intersample=True):
+    flt = mm.Filter(src)
+    images = {"in": image} if image is not None else {}
+    return CpuFilter(flt.ir_json).render(w, h, uservals=uv, images=images, t=t, intersample=intersample)
+
+
+# ---- the oracle is pinned by the reference's own golden vectors --------------------------
+GOLDEN = [
+    ("mandelbrot", "render_mandelbrot.png", {}, False, 0),
+    ("ident", "utilities_ident.png", {}, True, 0),
+    ("pond", "distorts_pond.png", {}, True, 0),
+    ("gaussian_blur", "blur_gaussian_blur.png", {"dev": 0.1}, True, 0),
+    # float-complex glibc functions: the golden was made with an older glibc; the survey
+    # measured the same 24 values off by one with a hand-written C restatement
+    ("droste", "map_droste.png", {}, True, 1),
+    ("closure_value", "apply.png", {}, False, 0),
+    ("closure_call", "circle.png", {}, True, 0),
+    ("closure_arg", "closure.png", {}, True, 0),
+    ("nested_calls", "twice.png", {}, True, 0),
+]
+
+
+@pytest.mark.parametrize("name,golden,uv,needs,tol", GOLDEN)
+def test_oracle_matches_reference_golden(name, golden, uv, needs, tol, marlene):
+    got = oracle_render(W.ALL[name], uv, marlene if needs else None)
+    want = load_png_rgb(golden)
+    d = np.abs(got[:, :, :3].astype(int) - want.astype(int))
+    assert d.max() <= tol
+    if name == "droste":
+        assert (d > 0).sum() <= 40
+
+
+def test_ident_golden_equals_input(marlene):
+    assert np.array_equal(load_png_rgb("utilities_ident.png"), marlene)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present")
+@pytest.mark.parametrize("name,path,uv", [
+    ("mandelbrot", "examples/Render/Mandelbrot.mm", {}), ("ident", "examples/Utilities/Ident.mm", {}),
+    ("pond", "examples/Distorts/Pond.mm", {}), ("gaussian_blur", "examples/Blur/Gaussian Blur.mm", {"dev": 0.07}),
+    ("droste", "examples/Map/Droste.mm", {}), ("droste", "examples/Map/Droste.mm", {"NoTransparency": 1}),
+    ("droste", "examples/Map/Droste.mm", {"ShowGrid": 1, "ShowFrame": 1, "HyperDroste": 1, "Untwist": 1}),
+    ("droste", "examples/Map/Droste.mm", {"ShowBothPoles": 1, "AutoSetPeriodicity": 1, "MirrorEffect": 1, "Strands": 2}),
+    ("droste", "examples/Map/Droste.mm", {"TilePoles": 1, "FractalPoints": 3, "ExternalTransparency": 1,
+                                          "LevelFrequency": 2, "StartingLevel": 2}),
+    ("closure_value", "tests/Apply.mm", {}), ("closure_call", "tests/Circle.mm", {}),
+    ("closure_arg", "tests/Closure.mm", {}), ("nested_calls", "tests/Twice.mm", {}),
+])
+def test_workload_text_equals_reference_script(name, path, uv, marlene):
+    """Our statements of the benchmark filters compute exactly what the reference's scripts do."""
+    theirs = open(os.path.join(REFERENCE, path)).read()
+    for t in (0.0, 0.3):
+        a = oracle_render(W.ALL[name], uv, marlene, t=t)
+        b = oracle_render(theirs, uv, marlene, t=t)
+        assert np.array_equal(a, b)
+
+
+# ---- golden sweep over the reference's test-suite where the filters are supported --------
+def _run_tests_cases():
+    """Parses tests/run_tests.sh of the reference: (script, golden, {-D values}, needs image)."""
+    path = os.path.join(REFERENCE, "tests", "run_tests.sh")
+    if not os.path.exists(path):
+        return []
+    cases = []
+    for line in open(path):
+        m = re.match(r'\s*run_(modify|render)_test\s+("[^"]+"|\S+)\s+(\S+)\s*(.*)$', line)
+        if not m:
+            continue
+        kind, script, golden, rest = m.groups()
+        script = script.strip('"')
+        uv = {k: float(v) for k, v in re.findall(r"-D(\w+)=([-\d.]+)", rest)}
+        cases.append((script, golden, uv, kind == "modify"))
+    return cases
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present")
+def test_oracle_sweep_over_reference_suite(marlene):
+    """Every case of the reference's run_tests.sh that our front-end + oracle support must
+    match its golden within 1 LSB (discontinuous filters: <0.1% of values further off)."""
+    cases = _run_tests_cases()
+    assert len(cases) >= 70
+    results = {}
+    for script, golden, uv, needs in cases:
+        p = os.path.join(REFERENCE, "tests", script)
+        try:
+            src = open(p).read()
+            got = oracle_render(src, uv, marlene if needs else None)
+        except Exception as e:  # unsupported feature: recorded, not a failure of this test
+            results[golden] = "unsupported: %s" % str(e).splitlines()[0][:80]
+            continue
+        want = load_png_rgb(golden)
+        d = np.abs(got[:, :, :3].astype(int) - want.astype(int))
+        results[golden] = (int(d.max()), int((d > 1).sum()))
+    ok = [g for g, r in results.items() if isinstance(r, tuple) and (r[0] <= 1 or r[1] < 0.001 * 256 * 256 * 3)]
+    bad = {g: r for g, r in results.items() if isinstance(r, tuple) and g not in ok}
+    unsupported = {g: r for g, r in results.items() if not isinstance(r, tuple)}
+    report = os.path.join(ROOT, "tests", "golden_sweep_report.json")
+    json.dump({"matching": sorted(ok), "mismatching": bad, "unsupported": unsupported}, open(report, "w"), indent=1)
+    assert not bad, bad
+    assert len(ok) >= 55, (len(ok), unsupported)
+
+
+# ---- host logic ----------------------------------------------------------------------------
+def test_parse_errors_are_reported():
+    for bad, msg in [("filter f () [1,2] end", "rgba:4"), ("filter f () q end", "Undefined variable"),
+                     ("filter f (int a, int a) grayColor(1) end", "declared more than once"),
+                     ("filter f () x = 1; grayColor(1) end", "Cannot assign to internal"),
+                     ("filter f () v = 1; v = [1,2]; grayColor(v) end", "two different types"),
+                     ("filter f () grayColor(1", "Parse error"),
+                     ("filter f () grayColor([1,2] + [1,2,3]) end", "Unable to resolve")]:
+        with pytest.raises(mm.MathMapError) as e:
+            mm.Filter(bad)
+        assert msg in str(e.value), (bad, str(e.value))
+
+
+def test_overload_resolution_and_types():
+    f = mm.Filter("filter f (float a: 0-1 (0.5)) z = ri:[a, 2]; w = z * z + 1; grayColor(abs(w)) end")
+    ops = []
+
+    def walk(b):
+        for s in b:
+            if s["k"] == "assign" and s["rhs"]["k"] == "op":
+                ops.append(s["rhs"]["op"])
+            for k in ("then", "else", "body"):
+                if k in s:
+                    walk(s[k])
+    walk(f.ir["body"])
+    assert "hypot" in ops and "MUL" in ops
+    types = {v["id"]: v["type"] for v in f.ir["vars"]}
+    assert "float" in types.values() and "int" in types.values()
+
+
+def test_frame_constant_code_is_hoisted():
+    """Droste's user-value-only set-up must land in the prologue slice, the per-pixel slice
+    must still contain the complex log/exp chain."""
+    ir = mm.Filter(W.DROSTE).ir
+
+    def count(b, key, pred):
+        n = 0
+        for s in b:
+            if s["k"] == "assign" and s[key] and pred(s):
+                n += 1
+            for k in ("then", "else", "body"):
+                if k in s:
+                    n += count(s[k], key, pred)
+        return n
+    is_op = lambda name: (lambda s: s["rhs"]["k"] == "op" and s["rhs"]["op"] == name)
+    assert count(ir["body"], "hoisted", is_op("atan")) >= 1
+    assert count(ir["body"], "pixel", is_op("clogf")) >= 1
+    assert count(ir["body"], "hoisted", is_op("ORIG_VAL")) == 0
+
+
+def test_all_workloads_compile_for_gfx950_offline():
+    for name, src in W.ALL.items():
+        f = mm.Filter(src)
+        assert "extern \"C\" __global__ void mm_pixels" in f.kernel_source
+        assert f.jit(load=False) > 1000, name
+
+
+def test_generated_c_of_oracle_has_reference_shape():
+    src = CpuFilter(mm.Filter(W.MANDELBROT).ir_json).source
+    assert "CALC_VIRTUAL_Y(row + A->region_y" in src and "while (" in src and "mmo_store_pixel" in src
+
+
+# ---- C-ABI surface ------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    l = C.CDLL(LIB_PATH)
+    declared = set()
+    for hdr in ("mmhip.h", "mathmap_hip_backend.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b((?:mmhip|mathmap_hip|gen_and_load_hip|unload_hip)_?\w*)\s*\(", text))
+    declared -= {"mmabi_get_pixel_func_t"}
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(l, name), "symbol %s declared in include/ but not exported" % name
+    for name in list(SYMBOLS) + list(BACKEND_SYMBOLS):
+        assert hasattr(l, name)
+
+
+def test_abi_struct_layouts_match_lp64_expectations():
+    """sizeof/offsetof of the reference-layout mirrors (include/mathmap_abi.h) as the host C
+    compiler sees them; the expected numbers are derived by hand from the reference headers."""
+    import subprocess
+    import tempfile
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "mathmap_abi.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mmabi_userval_t), sizeof(mmabi_mathmap_pools_t),
+         offsetof(mmabi_invocation_t, img_width), offsetof(mmabi_invocation_t, row_stride),
+         offsetof(mmabi_image_t, v), sizeof(mmabi_primary_t), sizeof(mmabi_rhs_t),
+         offsetof(mmabi_statement_t, parent), offsetof(mmabi_slice_t, region_x), sizeof(mmabi_value_t));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    got = [int(x) for x in out]
+    # userval_t: union{.., struct{GimpRGB(32) + color_t}=40} + GtkObject* = 48
+    # mathmap_pools_t: int + pad + pools_t(4+pad+8+20*8=176) + ptr = 192
+    # invocation: mathmap*(8) uservals*(8) antialiasing(4)+pad(4) orig_val_func(8) supersampling(4) output_bpp(4)
+    #             edge_x,y(8) edge colours(8) -> img_width at 56; ... image_R at 72, row_stride at 76
+    assert got[0] == 48 and got[1] == 192
+    assert got[2] == 56 and got[3] == 76
+    assert got[4] == 16            # image_t: 4 ints then the union
+    assert got[5] == 16            # primary_t: kind, const_type, 8-byte union
+    assert got[6] == 8 + 8 + 9 * 16  # rhs_t: kind(+pad), op*, 9 primaries
+    assert got[7] == 8 + 32        # statement_t: kind(+pad), 32-byte union, then parent
+    assert got[8] == 16            # slice: frame*, 2 floats, region_x
+    assert got[9] == 48
+
+
+# ---- multi-process striping (gloo, world_size 2) ------------------------------------------------
+def test_row_stripe_partition_is_a_partition():
+    from mathmap_amd.striping import stripe_rows
+    for h in (1, 7, 256, 8192, 16384):
+        for g in (1, 2, 3, 8):
+            rows = [stripe_rows(h, r, g) for r in range(g)]
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(g - 1))

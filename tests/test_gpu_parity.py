@@ -121,3 +121,33 @@ def test_mandelbrot_8192_stripe_property():
         assert np.array_equal(got[lo:lo + 8], want[lo:lo + 8])
     # symmetric in y for the default parameters: row r mirrors row h-1-r
     assert np.array_equal(got[:64], got[::-1][:64])
+
+
+@pytest.mark.parametrize("name,bands", [("mandelbrot", 1), ("pond", 3), ("droste", 2), ("gaussian_blur", 1),
+                                        ("closure_arg", 2)])
+def test_reference_abi_boundary_roundtrip(name, bands, marlene):
+    """gen_and_load_hip_code + the returned mathfuncs, driven with reference-layout
+    structures (include/mathmap_abi.h) the way mathmap_common.c drives the cc backend,
+    must produce the same frame as the standalone C API."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = 256, 256
+    src = W.ALL[name]
+    needs = "image in" in src
+    uv = {"dev": 0.0} if name == "gaussian_blur" else {}
+    flt = mm.Filter(src)
+    inv = flt.invoke(w, h)
+    if needs:
+        inv.set_image("in", marlene)
+    want = inv.render(t=0.25)
+    got = np.zeros((h, w, 4), np.uint8)
+    img = np.ascontiguousarray(marlene)
+    rc = lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p) if needs else None,
+                                            img.shape[1], img.shape[0], 3, w, h, 0.25, bands,
+                                            got.ctypes.data_as(C.c_void_p))
+    if name == "gaussian_blur":
+        # default dev = 0 -> sigma 0 -> the FIR path, which the GPU backend reports as unsupported
+        assert rc != 0
+        return
+    assert rc == 0, lib().mmhip_selftest_error().decode()
+    assert np.array_equal(got, want)
