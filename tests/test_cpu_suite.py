@@ -171,7 +171,7 @@ def test_frame_constant_code_is_hoisted():
 def test_all_workloads_compile_for_gfx950_offline():
     for name, src in W.ALL.items():
         f = mm.Filter(src)
-        assert "extern \"C\" __global__ void mm_pixels" in f.kernel_source
+        assert "mm_pixels(mm_args A" in f.kernel_source
         assert f.jit(load=False) > 1000, name
 
 
