@@ -107,6 +107,13 @@ struct Generator {
         }
     }
 
+    // is `v` nameable from code of slice `sl` (defined there, or transferred into it)?
+    bool value_visible(const Value *v, Slice sl) const {
+        if (v->index < 0) return true;
+        if (sl == PROLOGUE) return v->hoisted;
+        return !v->hoisted || transfer_off.count(const_cast<Value *>(v)) > 0;
+    }
+
     static const char *libm_name(const char *cname) {
         static const std::pair<const char *, const char *> table[] = {
             {"sqrt", "mm_sqrt"}, {"hypot", "mm_hypot"}, {"sin", "mm_sin"}, {"cos", "mm_cos"}, {"tan", "mm_tan"},
@@ -160,6 +167,18 @@ struct Generator {
                                         "SET_DEBUG_TUPLE_DATA", "OUTPUT_TUPLE"})
                     if (!strcmp(cn, bad)) throw CompileError(std::string("HIP backend: op ") + cn + " is not supported yet");
                 if (!strcmp(cn, "PRINT_FLOAT") || !strcmp(cn, "NEWLINE")) return "0";
+                // escape-time test `sqrt(a) < 2^k`  ->  0 <= a < 4^k (exact, see mm_device.h)
+                if (opt.fast_math_exact && !strcmp(cn, "LESS") && r.args[0].kind == Primary::Val && r.args[1].is_const()) {
+                    const Stmt *d = r.args[0].value->def;
+                    double k = r.args[1].kind == Primary::IntConst ? (double)r.args[1].i
+                             : r.args[1].kind == Primary::FloatConst ? (double)r.args[1].f : -1.0;
+                    int ex = 0;
+                    bool pow2 = k > 0 && std::frexp(k, &ex) == 0.5 && ex > -50 && ex < 50;
+                    if (pow2 && d && d->kind == Stmt::Assign && d->rhs.kind == Rhs::Op && !strcmp(d->rhs.op->cname, "sqrt") &&
+                        d->lhs->var->type == Ty::Float && d->rhs.args[0].type() == Ty::Float &&
+                        d->rhs.args[0].kind == Primary::Val && value_visible(d->rhs.args[0].value, sl))
+                        return "MM_SQRT_LESS_POW2(" + prim(d->rhs.args[0], sl) + ", " + float_literal((float)(k * k)) + "f)";
+                }
                 std::string name = cn;
                 if (const char *lm = libm_name(cn)) name = lm;
                 // exact f32 fast path: (float)sqrt((double)f) == sqrtf(f), correctly rounded
@@ -375,8 +394,11 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         // ---- prologue ----
         ks.prologue_name = "mm_prologue";
         ks.pixel_name = "mm_pixels";
-        out << "extern \"C\" __global__ void mm_prologue(mm_args A, char *XY) {\n";
-        out << "  if (blockIdx.x != 0 || threadIdx.x != 0) return;\n  MM_INTERNALS\n";
+        out << "extern \"C\" __global__ void __launch_bounds__(256) mm_prologue(mm_args A, char *XY) {\n";
+        out << "  {\n    const int gid = blockIdx.x * 256 + threadIdx.x;\n"
+               "    if (gid < A.region_width) A.xtab[gid] = CALC_VIRTUAL_X(gid + A.region_x, A.frame_render_width, A.sampling_offset_x);\n"
+               "    if (gid < A.num_rows) A.ytab[gid] = CALC_VIRTUAL_Y(A.first_row + gid, A.frame_render_height, A.sampling_offset_y);\n"
+               "    if (gid != 0) return;\n  }\n  MM_INTERNALS\n";
         decls(pro_defs, "  ");
         stmts(code.body, PROLOGUE, "  ");
         for (Value *v : transfer_order)
@@ -397,9 +419,8 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
   const int col = tile_x * MM_TILE_W + (threadIdx.x % MM_TILE_W);
   const int rl = tile_y * MM_TILE_H + (threadIdx.x / MM_TILE_W);   // row within this launch
   if (col >= A.region_width || rl >= A.num_rows) return;
-  const int row = A.first_row + rl;                                 // absolute row
-  const float y = CALC_VIRTUAL_Y(row, A.frame_render_height, A.sampling_offset_y);
-  const float x = CALC_VIRTUAL_X(col + A.region_x, A.frame_render_width, A.sampling_offset_x);
+  const float y = A.ytab[rl];    // CALC_VIRTUAL_Y(first_row + rl, ...), computed once per row by the prologue
+  const float x = A.xtab[col];   // CALC_VIRTUAL_X(col + region_x, ...), once per column
   (void)x; (void)y;
 )";
         for (Value *v : transfer_order)

@@ -81,6 +81,12 @@ struct mm_args {
     void *out;
     int native_slot_base;             // image-table index of native-filter result 0
     int pad0;
+    // per-column x and per-row y virtual coordinates of this launch, filled by the
+    // prologue kernel (the reference's y_vars / per-row x-const code,
+    // new_template.c.in:245,260,357-372): the double divide is done once per row and
+    // column instead of once per pixel.
+    float *xtab;
+    float *ytab;
 };
 
 // ---- op macros (opmacros.h:30-47) --------------------------------------------------
@@ -129,7 +135,12 @@ MM_DEV double mm_beta(double a, double b) { return exp(lgamma(a) + lgamma(b) - l
 
 // (float)sqrt((double)x) == correctly rounded sqrtf(x) for every float x (53 >= 2*24+2
 // bits: double rounding is innocuous for sqrt), so float operands may take the f32 path.
-MM_DEV float mm_sqrt_f32(float a) { return __fsqrt_rn(a); }
+MM_DEV float mm_sqrt_f32(float a) { return sqrtf(a); }   // correctly rounded (v_sqrt_f32 + fma fix-up); __fsqrt_rn is the 1-ulp form
+// sqrt_rn(a) < K for K a power of two  <=>  0 <= a < K*K : sqrt is monotone, sqrt(K*K) = K
+// exactly, and sqrt(pred(K*K)) = K*sqrt(1 - 2^-24) = K*(1 - 2^-25 - ...) lies below the
+// midpoint of pred(K) and K, so it rounds to pred(K) < K.  NaN and negative a give false on
+// both sides (-0 gives true on both).  Saves the sqrt in escape-time tests `abs(z) < 2`.
+#define MM_SQRT_LESS_POW2(a, k2) (((a) < (k2)) && ((a) >= 0.0f))
 
 // ---- complex (float _Complex) -----------------------------------------------------------
 // In the generated C, complex values only flow COMPLEX() -> c*f() -> crealf/cimagf
@@ -283,10 +294,14 @@ MM_DEV mm_complex cgamma(mm_complex zf) {
 #define GREEN(c) (((c) >> 16) & 0xff)
 #define BLUE(c) (((c) >> 8) & 0xff)
 #define ALPHA(c) ((c)&0xff)
-#define RED_FLOAT(c) (RED(c) / 255.0)
-#define GREEN_FLOAT(c) (GREEN(c) / 255.0)
-#define BLUE_FLOAT(c) (BLUE(c) / 255.0)
-#define ALPHA_FLOAT(c) (ALPHA(c) / 255.0)
+// (float)(c / 255.0) == (float)(c * (1.0 / 255.0)) for every c in 0..255 (enumerated in
+// tests/test_cpu_suite.py::test_byte_to_float_identity), so the double divide of
+// opmacros.h:147-150 becomes a double multiply; the value assigned to a float is identical.
+#define MM_BYTE_TO_UNIT(c) ((double)(c) * (1.0 / 255.0))
+#define RED_FLOAT(c) MM_BYTE_TO_UNIT(RED(c))
+#define GREEN_FLOAT(c) MM_BYTE_TO_UNIT(GREEN(c))
+#define BLUE_FLOAT(c) MM_BYTE_TO_UNIT(BLUE(c))
+#define ALPHA_FLOAT(c) MM_BYTE_TO_UNIT(ALPHA(c))
 #define MAKE_COLOR(r, g, b, a) \
     (MAKE_RGBA_COLOR(CLAMP01((r)) * 255, CLAMP01((g)) * 255, CLAMP01((b)) * 255, CLAMP01((a)) * 255))
 #define TUPLE_NTH(t, n) ((t).v[(n)])
@@ -370,19 +385,25 @@ MM_DEV color_t mm_orig_val_pixel(const mm_args &A, const mm_image_desc &d, float
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
 #if !MM_SUPERSAMPLING
-    x += 0.5;   // double add, rounded back to float
-    y += 0.5;
+    // reference: `x += 0.5` (double add, rounded back to float).  The double sum of a float
+    // and 0.5 is exact below 2^52, so rounding it to float equals the correctly rounded
+    // float add; above that both leave x unchanged.
+    x = x + 0.5f;
+    y = y + 0.5f;
 #endif
-    return mm_get_pixel(A, d, (int)floor((double)x), (int)floor((double)y), frame);
+    // floor((double)x) of a float is the float floor: identical integer
+    return mm_get_pixel(A, d, (int)floorf(x), (int)floorf(y), frame);
 }
 
 MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
-    int x1 = (int)floor((double)x), x2 = x1 + 1;
-    int y1 = (int)floor((double)y), y2 = y1 + 1;
+    int x1 = (int)floorf(x), x2 = x1 + 1;     // == floor((double)x)
+    int y1 = (int)floorf(y), y2 = y1 + 1;
     float x2fact = x - x1, y2fact = y - y1;
-    float x1fact = 1.0 - x2fact, y1fact = 1.0 - y2fact;
+    // reference: 1.0 - x2fact in double, rounded to float: the double difference is exact,
+    // so this is the correctly rounded float subtraction
+    float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
     float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
     color_t p1 = mm_get_pixel(A, d, x1, y1, frame), p2 = mm_get_pixel(A, d, x1, y2, frame);
     color_t p3 = mm_get_pixel(A, d, x2, y1, frame), p4 = mm_get_pixel(A, d, x2, y2, frame);

@@ -43,6 +43,8 @@ struct HArgs {
     void *out;
     int native_slot_base;
     int pad0;
+    float *xtab;
+    float *ytab;
 };
 
 struct HNativeArg { int kind; int i; float f; HImage img; };
@@ -51,6 +53,6 @@ struct HNativeRec { int executed; int index; int nargs; int pad; HNativeArg args
 static_assert(sizeof(HImage) == 24, "mm_image layout");
 static_assert(sizeof(HImageDesc) == 56, "mm_image_desc layout");
 static_assert(sizeof(HNativeArg) == 36, "mm_narg_t layout");
-static_assert(sizeof(HArgs) == 136, "mm_args layout");
+static_assert(sizeof(HArgs) == 152, "mm_args layout");
 
 }  // namespace mm

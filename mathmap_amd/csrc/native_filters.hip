@@ -101,61 +101,158 @@ __global__ void __launch_bounds__(256) k_render_drawable(const uint32_t *__restr
     out[i] = t;
 }
 
-// ---- K3/K4 (first version): one lane per line of one channel ------------------------------------
-// Line L has `n` elements at map[base(L) + k*estride].  Causal sweep stores vp (double) to
-// scratch, anticausal sweep adds vm and stores the float result in place.  History of the
-// last four inputs / outputs lives in registers.
-struct LineGeom { long n_lines; int n; long estride; int vertical; int w; };
+// ---- K3/K4: recursive Gaussian along one axis, output written transposed ---------------------
+// Input layout  in[k][line][ch]   (element k of line `line`: ((k*lines + line)*4 + ch) floats)
+// Output layout out[line][k][ch]  (transposed), so running the same kernel pair twice does
+// vertical (lines = columns) then horizontal (lines = rows of the original) and ends in the
+// original layout -- no separate transpose pass, and every global access is coalesced:
+//   * one lane per (line, channel): consecutive lanes read consecutive floats of a row of `in`;
+//   * the causal sweep streams its f64 partials to scratch[k][line*4+ch] (coalesced);
+//   * the anticausal sweep stages 16 finished steps x 16 lines per wave in LDS and writes
+//     them as 256-byte runs of the transposed map.
+// The sweeps are sequential along k by definition (4th-order recurrences in the reference's
+// exact operation order); the only parallelism is lines x channels, so memory latency is
+// hidden by prefetching IIR_U steps ahead in registers rather than by occupancy.
+#define IIR_U 16
 
-__device__ __forceinline__ long line_base(const LineGeom &g, long L) {
-    // vertical: L = col*4+ch -> base L ; horizontal: L = row*4+ch -> row*w*4 + ch
-    return g.vertical ? L : (L >> 2) * (long)g.w * 4 + (L & 3);
+struct LineArgs { int n; int lines; };
+
+__device__ __forceinline__ double iir_step(double s0, double s1, double s2, double s3, double s4, double v1, double v2,
+                                           double v3, double v4, const double *n, const double *d) {
+    // gauss.c:181-185 with terms = 4: acc starts at 0 and adds (n[i]*s[k-i] - d[i]*v[k-i]) for i = 0..4
+    double acc = 0.0;
+    acc += n[0] * s0 - d[0] * acc;
+    acc += n[1] * s1 - d[1] * v1;
+    acc += n[2] * s2 - d[2] * v2;
+    acc += n[3] * s3 - d[3] * v3;
+    acc += n[4] * s4 - d[4] * v4;
+    return acc;
 }
 
-__global__ void __launch_bounds__(256) k_iir_lines(float *__restrict__ map, double *__restrict__ scratch, LineGeom g,
-                                                   IirCoef c) {
+// steps 0..3 of a sweep (gauss.c:178-190: fewer than 4 predecessors, the rest uses the edge value)
+__device__ __forceinline__ double iir_edge_step(int j, double s0, double s1, double s2, double s3, double v1, double v2,
+                                                double v3, const double *n, const double *d, const double *bd,
+                                                float initial) {
+    double acc = 0.0;
+    acc += n[0] * s0 - d[0] * acc;
+    if (j >= 1) acc += n[1] * s1 - d[1] * v1; else acc += (n[1] - bd[1]) * initial;
+    if (j >= 2) acc += n[2] * s2 - d[2] * v2; else acc += (n[2] - bd[2]) * initial;
+    if (j >= 3) acc += n[3] * s3 - d[3] * v3; else acc += (n[3] - bd[3]) * initial;
+    acc += (n[4] - bd[4]) * initial;
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) k_iir_causal(const float *__restrict__ in, double *__restrict__ scratch,
+                                                    LineArgs g, IirCoef c) {
     const long L = (long)blockIdx.x * 256 + threadIdx.x;
-    if (L >= g.n_lines) return;
-    float *p = map + line_base(g, L);
-    double *sc = scratch + L;             // scratch[k][n_lines]: coalesced across lanes
+    const long stride = (long)g.lines * 4;
+    if (L >= stride) return;
+    const float *p = in + L;
+    double *sc = scratch + L;
     const int n = g.n;
-    const long es = g.estride;
-    // ---- causal ----
+    const float initial = p[0];
+    double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+    int k = 0;
+    for (; k < 4 && k < n; ++k) {
+        const double s0 = (double)p[(long)k * stride];
+        const double acc = iir_edge_step(k, s0, s1, s2, s3, v1, v2, v3, c.n_p, c.d_p, c.bd_p, initial);
+        sc[(long)k * stride] = acc;
+        s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+        v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+    }
+    float cur[IIR_U], nxt[IIR_U];
+#pragma unroll
+    for (int u = 0; u < IIR_U; ++u) cur[u] = (k + u < n) ? p[(long)(k + u) * stride] : 0.0f;
+    for (; k < n; k += IIR_U) {
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) nxt[u] = (k + IIR_U + u < n) ? p[(long)(k + IIR_U + u) * stride] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) {
+            if (k + u < n) {
+                const double s0 = (double)cur[u];
+                const double acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
+                sc[(long)(k + u) * stride] = acc;
+                s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) cur[u] = nxt[u];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_iir_anticausal_T(const float *__restrict__ in, const double *__restrict__ scratch,
+                                                          float *__restrict__ outT, LineArgs g, IirCoef c) {
+    // wave-private staging tile: 16 lines x IIR_U steps x 4 channels, line stride padded by 4 floats
+    __shared__ float tile[4][16 * (IIR_U * 4 + 4)];
+    const long L = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)g.lines * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tw = tile[wave];
+    const int ll = lane >> 2, ch = lane & 3;                // line within the wave's 16, channel
+    const long line0 = ((long)blockIdx.x * 256 + (long)wave * 64) >> 2;   // first line of this wave
+    const bool active = L < stride;
+    const float *p = in + (active ? L : 0);
+    const double *sc = scratch + (active ? L : 0);
+    const int n = g.n;
+    const float initial = p[(long)(n - 1) * stride];
+    double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+    // process blocks of IIR_U steps from the end; block b covers k in [kb, kb+IIR_U)
+    const int nblocks = (n + IIR_U - 1) / IIR_U;
+    float cur_s[IIR_U], nxt_s[IIR_U];
+    double cur_v[IIR_U], nxt_v[IIR_U];
     {
-        const float initial = p[0];
-        double s1 = 0, s2 = 0, s3 = 0, s4 = 0;   // inputs k-1..k-4
-        double v1 = 0, v2 = 0, v3 = 0, v4 = 0;   // outputs k-1..k-4
-        for (int k = 0; k < n; ++k) {
-            const double s0 = (double)p[(long)k * es];
-            double acc = 0.0;
-            acc += c.n_p[0] * s0 - c.d_p[0] * acc;
-            if (k >= 1) acc += c.n_p[1] * s1 - c.d_p[1] * v1; else acc += (c.n_p[1] - c.bd_p[1]) * initial;
-            if (k >= 2) acc += c.n_p[2] * s2 - c.d_p[2] * v2; else acc += (c.n_p[2] - c.bd_p[2]) * initial;
-            if (k >= 3) acc += c.n_p[3] * s3 - c.d_p[3] * v3; else acc += (c.n_p[3] - c.bd_p[3]) * initial;
-            if (k >= 4) acc += c.n_p[4] * s4 - c.d_p[4] * v4; else acc += (c.n_p[4] - c.bd_p[4]) * initial;
-            sc[(long)k * g.n_lines] = acc;
-            s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-            v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+        const int kb = (nblocks - 1) * IIR_U;
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) {
+            const int k = kb + u;
+            cur_s[u] = (k < n) ? p[(long)k * stride] : 0.0f;
+            cur_v[u] = (k < n) ? sc[(long)k * stride] : 0.0;
         }
     }
-    // ---- anticausal ----
-    {
-        const float initial = p[(long)(n - 1) * es];
-        double s1 = 0, s2 = 0, s3 = 0, s4 = 0;   // inputs k+1..k+4
-        double v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-        for (int k = n - 1, j = 0; k >= 0; --k, ++j) {
-            const double s0 = (double)p[(long)k * es];
-            double acc = 0.0;
-            acc += c.n_m[0] * s0 - c.d_m[0] * acc;
-            if (j >= 1) acc += c.n_m[1] * s1 - c.d_m[1] * v1; else acc += (c.n_m[1] - c.bd_m[1]) * initial;
-            if (j >= 2) acc += c.n_m[2] * s2 - c.d_m[2] * v2; else acc += (c.n_m[2] - c.bd_m[2]) * initial;
-            if (j >= 3) acc += c.n_m[3] * s3 - c.d_m[3] * v3; else acc += (c.n_m[3] - c.bd_m[3]) * initial;
-            if (j >= 4) acc += c.n_m[4] * s4 - c.d_m[4] * v4; else acc += (c.n_m[4] - c.bd_m[4]) * initial;
-            const double vp = sc[(long)k * g.n_lines];
-            p[(long)k * es] = (float)(vp + acc);
-            s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-            v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+    for (int b = nblocks - 1; b >= 0; --b) {
+        const int kb = b * IIR_U;
+        if (b > 0) {
+#pragma unroll
+            for (int u = 0; u < IIR_U; ++u) {
+                nxt_s[u] = p[(long)(kb - IIR_U + u) * stride];
+                nxt_v[u] = sc[(long)(kb - IIR_U + u) * stride];
+            }
         }
+#pragma unroll
+        for (int u = IIR_U - 1; u >= 0; --u) {
+            const int k = kb + u;
+            if (k < n) {
+                const int j = n - 1 - k;                     // steps from the end
+                const double s0 = (double)cur_s[u];
+                double acc;
+                if (j < 4) acc = iir_edge_step(j, s0, s1, s2, s3, v1, v2, v3, c.n_m, c.d_m, c.bd_m, initial);
+                else acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
+                tw[ll * (IIR_U * 4 + 4) + u * 4 + ch] = (float)(cur_v[u] + acc);   // transfer_pixels, gauss.c:117-124
+                s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+            }
+        }
+        // the tile is private to this wave: a wave-level fence suffices
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // write 16 lines x 16 steps transposed: lane -> (line = i*4 + lane/16, step = lane%16)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tl = i * 4 + (lane >> 4), kk = lane & 15;
+            const long line = line0 + tl;
+            const int k = kb + kk;
+            if (line < g.lines && k < n) {
+                const float4 v = *(const float4 *)&tw[tl * (IIR_U * 4 + 4) + kk * 4];
+                *(float4 *)&outT[(line * (long)n + k) * 4] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) { cur_s[u] = nxt_s[u]; cur_v[u] = nxt_v[u]; }
     }
 }
 
@@ -192,19 +289,31 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         *err = "gaussian_blur: sigma < 0.5 px (the reference's RLE/FIR path, gauss.c:500-639) is not implemented on the GPU yet";
         return -1;
     }
-    size_t lines = (size_t)std::max(w, h) * 4;
-    double *scratch = (double *)ws.reserve((size_t)w * h * 4 * sizeof(double));
-    (void)lines;
-    if (!scratch) { *err = "gaussian_blur: out of device memory for the scan scratch"; return -1; }
+    // workspace: f64 scan scratch (w*h*4 doubles) followed by the transposed intermediate map
+    const size_t scratch_bytes = (size_t)w * h * 4 * sizeof(double);
+    const size_t map_bytes = (size_t)w * h * 4 * sizeof(float);
+    char *wsp = (char *)ws.reserve(scratch_bytes + map_bytes);
+    if (!wsp) { *err = "gaussian_blur: out of device memory for the scan workspace"; return -1; }
+    double *scratch = (double *)wsp;
+    float *mapT = (float *)(wsp + scratch_bytes);
     IirCoef c;
-    // vertical pass first (gauss.c:155-201)
+    // vertical pass first (gauss.c:155-201): lines = columns, n = h; result transposed into mapT[w][h][4]
     find_iir_constants(c, vs);
-    LineGeom gv{(long)w * 4, h, (long)w * 4, 1, w};
-    k_iir_lines<<<(unsigned)((gv.n_lines + 255) / 256), 256, 0, s>>>(out_map, scratch, gv, c);
-    // horizontal pass (gauss.c:203-252)
+    {
+        LineArgs g{h, w};
+        const unsigned blocks = (unsigned)(((long)w * 4 + 255) / 256);
+        k_iir_causal<<<blocks, 256, 0, s>>>(out_map, scratch, g, c);
+        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(out_map, scratch, mapT, g, c);
+    }
+    // horizontal pass (gauss.c:203-252): in mapT the original rows are the "columns"; transposing again
+    // restores the original layout in out_map
     find_iir_constants(c, hs);
-    LineGeom gh{(long)h * 4, w, 4, 0, w};
-    k_iir_lines<<<(unsigned)((gh.n_lines + 255) / 256), 256, 0, s>>>(out_map, scratch, gh, c);
+    {
+        LineArgs g{w, h};
+        const unsigned blocks = (unsigned)(((long)h * 4 + 255) / 256);
+        k_iir_causal<<<blocks, 256, 0, s>>>(mapT, scratch, g, c);
+        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(mapT, scratch, out_map, g, c);
+    }
     if (hipGetLastError() != hipSuccess) { *err = "gaussian_blur: kernel launch failed"; return -1; }
     return 0;
 }

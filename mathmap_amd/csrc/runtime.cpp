@@ -274,6 +274,8 @@ void mmhip_invocation_free(mmhip_invocation *inv) {
     if (inv->d_uv) (void)hipFree(inv->d_uv);
     if (inv->d_images) (void)hipFree(inv->d_images);
     if (inv->d_xy) (void)hipFree(inv->d_xy);
+    if (inv->d_xtab) (void)hipFree(inv->d_xtab);
+    if (inv->d_ytab) (void)hipFree(inv->d_ytab);
     if (inv->d_curves) (void)hipFree(inv->d_curves);
     if (inv->d_gradients) (void)hipFree(inv->d_gradients);
     if (inv->ev0) (void)hipEventDestroy(inv->ev0);
@@ -520,10 +522,25 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     a.out = out_device;
     a.native_slot_base = inv->native_slot_base;
 
+    // coordinate tables (grown on demand; stream order protects re-use)
+    if (region_w > inv->xtab_cap) {
+        if (inv->d_xtab) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(inv->d_xtab); }
+        HIP_TRY(hipMalloc((void **)&inv->d_xtab, (size_t)region_w * sizeof(float)));
+        inv->xtab_cap = region_w;
+    }
+    if (a.num_rows > inv->ytab_cap) {
+        if (inv->d_ytab) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(inv->d_ytab); }
+        HIP_TRY(hipMalloc((void **)&inv->d_ytab, (size_t)a.num_rows * sizeof(float)));
+        inv->ytab_cap = a.num_rows;
+    }
+    a.xtab = inv->d_xtab;
+    a.ytab = inv->d_ytab;
+
     char *xy = inv->d_xy;
     void *params[] = {&a, &xy};
-    if (f->ks.has_prologue) {
-        HIP_TRY(hipModuleLaunchKernel(f->f_pro, 1, 1, 1, 64, 1, 1, 0, s, params, nullptr));
+    {
+        int n = std::max(region_w, a.num_rows);
+        HIP_TRY(hipModuleLaunchKernel(f->f_pro, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
         if (!f->ks.natives.empty() && run_natives(inv, a, s) != 0) return -1;
     }
     int tiles_x = (region_w + f->ks.tile_w - 1) / f->ks.tile_w;

@@ -45,6 +45,8 @@ struct mmhip_invocation {
     std::vector<unsigned long long> native_memo_gen;
     unsigned long long input_generation = 1;
     char *d_xy = nullptr;
+    float *d_xtab = nullptr, *d_ytab = nullptr;   // per-column / per-row coordinates of the current launch
+    int xtab_cap = 0, ytab_cap = 0;
     hipStream_t stream = nullptr;
     uint32_t edge_color_x = 0, edge_color_y = 0;
     float sampling_offset_x = 0.f, sampling_offset_y = 0.f;

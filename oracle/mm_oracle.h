@@ -176,5 +176,7 @@ void mmo_gauss_iir(float *map, int width, int height, float hdev, float vdev);
 void mmo_gauss_rle(float *map, int width, int height, float hdev, float vdev);
 void mmo_find_iir_constants(double *n_p, double *n_m, double *d_p, double *d_m, double *bd_p, double *bd_m, float std_dev);
 void mmo_free_memo(mmo_args *A, int nslots);
+float _Complex cgamma(float _Complex z);
+#define gsl_sf_beta(a, b) (exp(lgamma((a)) + lgamma((b)) - lgamma((a) + (b))))   /* GSL absent: parity unpinned */
 
 #endif

@@ -592,3 +592,25 @@ void mmo_gauss_rle(float *map, int width, int height, float hdev, float vdev) {
     if (vdev > 0.0) rle_pass(map, width, height, vdev, 1);
     if (hdev > 0.0) rle_pass(map, width, height, hdev, 0);
 }
+
+/* ---- cgamma (builtins/spec_func.c:35-64; Luke's approximation, double-complex inside) ---- */
+float _Complex cgamma(float _Complex z) {
+    static const double coeff[7] = {41.624436916439068, -51.224241022374774, 11.338755813488977, -0.747732687772388,
+                                    0.008782877493061, -1.899030264e-6, 1.946335e-9};
+    double _Complex s, H, w;
+    int n;
+    if (creal(z) < 0.0) {
+        double _Complex denom = 1.0;
+        int flr = -floor(creal(z));
+        for (n = 0; n < flr; ++n) denom = denom * (z + n);
+        return cgamma(z + flr) / denom;
+    }
+    w = z - 1.0;
+    s = coeff[0];
+    H = 1.0;
+    for (n = 1; n < 7; n++) {
+        H *= (w + 1 - n) / (w + n);
+        s += coeff[n] * H;
+    }
+    return (2.506628274631 * cexp(-w - 5.5) * cpow(w + 5.5, w + 0.5) * s);
+}

@@ -238,3 +238,71 @@ def test_row_stripe_partition_is_a_partition():
             rows = [stripe_rows(h, r, g) for r in range(g)]
             assert rows[0][0] == 0 and rows[-1][1] == h
             assert all(rows[i][1] == rows[i + 1][0] for i in range(g - 1))
+
+
+# ---- exactness claims behind the device-side strength reductions (mm_device.h) -----------------
+def test_byte_to_float_identity():
+    c = np.arange(256, dtype=np.float64)
+    assert np.array_equal((c / 255.0).astype(np.float32), (c * (1.0 / 255.0)).astype(np.float32))
+
+
+def test_sqrt_less_power_of_two_identity():
+    """sqrt_rn(a) < K  <=>  0 <= a < K*K for K a power of two, checked on every float in a
+    window of +-2^16 ulps around K*K and on random floats."""
+    rng = np.random.default_rng(0)
+    for k in (0.25, 0.5, 1.0, 2.0, 4.0, 1024.0):
+        k2 = np.float32(k * k)
+        bits = np.array([k2], np.float32).view(np.uint32)[0]
+        window = (np.arange(-65536, 65536, dtype=np.int64) + int(bits)).astype(np.uint32).view(np.float32)
+        rnd = rng.uniform(0, 4 * k * k, 200000).astype(np.float32)
+        special = np.array([0.0, -0.0, -1.0, np.nan, np.inf, -np.inf], np.float32)
+        with np.errstate(invalid="ignore"):
+            for a in (window, rnd, special):
+                lhs = np.sqrt(a) < np.float32(k)          # numpy's float32 sqrt is correctly rounded
+                rhs = (a < k2) & (a >= 0)
+                assert np.array_equal(lhs, rhs), k
+
+
+def test_float_add_half_and_floor_identities():
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-1e6, 1e6, 500000), rng.uniform(-4, 4, 500000)]).astype(np.float32)
+    assert np.array_equal((x.astype(np.float64) + 0.5).astype(np.float32), x + np.float32(0.5))
+    assert np.array_equal(np.floor(x.astype(np.float64)).astype(np.int64), np.floor(x).astype(np.int64))
+    f = rng.uniform(0, 1, 500000).astype(np.float32)
+    assert np.array_equal((1.0 - f.astype(np.float64)).astype(np.float32), np.float32(1.0) - f)
+
+
+def test_oracle_cgamma_matches_reference_build():
+    """oracle cgamma vs the reference's own builtins/spec_func.c compiled into oracle/_ref
+    (bit-identical), and the known answer of its TEST_CGAMMA main: cgamma(2.5+0.5i)."""
+    import subprocess
+    from oracle import ccgen
+    ref = os.path.join(ROOT, "oracle", "_ref", "libspec_func.so")
+    rt = ccgen.build_runtime()
+    so = os.path.join(ccgen.BUILD, "rt_only.so")
+    subprocess.run(["gcc", "-shared", "-o", so, rt, "-lm"], check=True)
+    prog = r'''
+#include <complex.h>
+#include <stdio.h>
+#include <dlfcn.h>
+typedef float _Complex (*fn)(float _Complex);
+int main(int argc, char **argv) {
+  fn mine = (fn)dlsym(dlopen(argv[1], RTLD_NOW), "cgamma");
+  fn ref = argc > 2 ? (fn)dlsym(dlopen(argv[2], RTLD_NOW), "cgamma") : 0;
+  float _Complex k = mine(2.5f + 0.5f * I);
+  printf("%f %f\n", crealf(k), cimagf(k));
+  int bad = 0;
+  if (ref) for (float x = -3.7f; x < 6.0f; x += 0.31f) for (float y = -4.0f; y < 4.0f; y += 0.37f) {
+    float _Complex a = mine(x + y * I), b = ref(x + y * I);
+    if (!(crealf(a) == crealf(b) && cimagf(a) == cimagf(b)) && !(crealf(a) != crealf(a) && crealf(b) != crealf(b))) ++bad;
+  }
+  printf("%d\n", bad);
+  return 0; }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.run(["gcc", "-O0", "-o", os.path.join(d, "t"), os.path.join(d, "t.c"), "-ldl", "-lm"], check=True)
+        args = [os.path.join(d, "t"), so] + ([ref] if os.path.exists(ref) else [])
+        out = subprocess.run(args, stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    assert abs(float(out[0]) - 1.172396) < 2e-6 and abs(float(out[1]) - 0.436507) < 2e-6
+    assert int(out[2]) == 0
