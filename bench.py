@@ -114,6 +114,17 @@ def main():
             k_ms = elapsed / args.steps * 1e3     # whole chain: render + 4 scan kernels + sample/pack
         bpp = ALGO_BYTES_PER_PIXEL[args.workload]
         achieved = w * h * bpp / (k_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, summarised by tools/pmc_traffic.py into profiles/): bench.py cannot run the
+        # profiler around itself, so it reports the committed per-launch figure for this
+        # exact workload/size, or null when none has been collected.
+        traffic = None
+        import glob
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s%d.json" % (args.workload, w)))):
+            try:
+                traffic = json.load(open(fn)).get("traffic_bytes_per_launch")
+            except Exception:
+                pass
         res = {
             "metric": "Mpixels/sec (%s @%dx%d)" % (args.workload, w, h),
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -124,7 +135,7 @@ def main():
                        "frames_per_step_per_gpu": 1, "parallelism": "frames x %d (no data-path collective)" % world,
                        "jit_seconds": round(jit_s, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mm_pixels", "kernel_ms": k_ms, "algorithmic_bytes_per_pixel": bpp},
         }
         if not args.no_cpu_baseline and world == 1:
