@@ -12,8 +12,10 @@
 // 16384^2 map is 4.29 GB; all intermediates stay on the device.
 #include "native_filters.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace mm {
 
@@ -256,6 +258,136 @@ __global__ void __launch_bounds__(256) k_iir_anticausal_T(const float *__restric
     }
 }
 
+// ---- K5: FIR path for sigma < 0.5 px on either axis (gauss.c:264-639) ----------------------------
+// make_rle_curve on the host (double exp, float taps), then per axis: a statistics kernel
+// (how many elements of a line repeat their successor -> run_length_encode's `same`) and a
+// stencil kernel that evaluates either do_full_lre or do_encoded_lre -- including the
+// latter's int-truncated cumulative sums (gauss.c:405) -- per line, like the reference's
+// `same > 3n/4` switch.  Lines are edge-replicated (gauss.c:333-375).
+struct FirArgs { int w, h, vertical, length; float total; int ctotal; };
+
+// gauss.c:264-306
+void make_rle_curve(double sigma, std::vector<float> &curve, std::vector<float> &sum, int &length, float &total) {
+    const double sigma2 = 2 * sigma * sigma;
+    const double l = sqrt(-sigma2 * log(1.0 / 255.0));
+    int n = (int)(ceil(l) * 2);
+    if ((n % 2) == 0) n += 1;
+    length = n / 2;
+    curve.assign(n, 0.f);            // curve[length + i], i in [-length, length]
+    curve[length] = 1.0f;
+    for (int i = 1; i <= length; i++) {
+        float temp = (float)exp(-(i * i) / sigma2);
+        curve[length - i] = temp;
+        curve[length + i] = temp;
+    }
+    sum.assign(2 * length + 1, 0.f); // sum[length + i]
+    for (int i = 1; i <= length * 2; i++) sum[i] = curve[i - 1] + sum[i - 1];
+    total = sum[2 * length] - sum[0];
+}
+
+__device__ __forceinline__ long fir_index(const FirArgs &g, int line, int k, int ch) {
+    return g.vertical ? ((long)k * g.w + line) * 4 + ch : ((long)line * g.w + k) * 4 + ch;
+}
+
+__global__ void __launch_bounds__(256) k_fir_same(const float *__restrict__ in, int *__restrict__ flags, FirArgs g) {
+    const long L = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lines = g.vertical ? g.w : g.h, n = g.vertical ? g.h : g.w;
+    if (L >= (long)lines * 4) return;
+    const int line = (int)(L >> 2), ch = (int)(L & 3);
+    float last = in[fir_index(g, line, n - 1, ch)];
+    int same = 0;
+    for (int k = n - 1; k >= 0; --k) {
+        const float c = in[fir_index(g, line, k, ch)];
+        if (c == last) same++;
+        else last = c;
+    }
+    flags[L] = same > (3 * n) / 4;
+}
+
+__global__ void __launch_bounds__(256) k_fir_apply(const float *__restrict__ in, float *__restrict__ out,
+                                                   const int *__restrict__ flags, const float *__restrict__ curve,
+                                                   const float *__restrict__ csum, FirArgs g) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)g.w * g.h * 4) return;
+    const int ch = (int)(e & 3);
+    const long px = e >> 2;
+    const int col = (int)(px % g.w), row = (int)(px / g.w);
+    const int line = g.vertical ? col : row, k = g.vertical ? row : col;
+    const int n = g.vertical ? g.h : g.w;
+    const int length = g.length;
+    const float *c = curve + length, *cs = csum + length;     // centred
+    auto pix = [&](int i) {                                    // edge-replicated line element
+        int kk = k + i;
+        kk = kk < 0 ? 0 : (kk >= n ? n - 1 : kk);
+        return in[fir_index(g, line, kk, ch)];
+    };
+    float val = 0.0f;
+    if (!flags[line * 4 + ch]) {
+        // do_full_lre, gauss.c:422-498
+        val += pix(0) * c[0];
+        for (int i = 1; i <= length; ++i) val += (pix(i) + pix(-i)) * c[i];
+        val = val / g.total;
+    } else {
+        // do_encoded_lre, gauss.c:380-420: walk the runs of equal values inside the window
+        int pos = -length;                 // window-relative position of the current run start
+        auto runlen = [&](int p) {         // equal elements from p onward (as far as the buffer goes)
+            const float v = pix(p);
+            int r = 1;
+            while (k + p + r < n + length && pix(p + r) == v) ++r;
+            return r;
+        };
+        float s1 = cs[-length];
+        int nb = runlen(pos);
+        int i = -length + nb;
+        while (i <= length) {
+            const int s2 = (int)cs[i];
+            val += pix(pos) * (s2 - s1);
+            s1 = (float)s2;
+            pos += nb;
+            nb = runlen(pos);
+            i += nb;
+        }
+        val += pix(pos) * (cs[length] - s1);
+        val = val / g.ctotal;
+    }
+    out[e] = val;
+}
+
+int gauss_rle(float *map, float *tmp, int w, int h, float hs, float vs, NativeWorkspace &ws, char *aux, hipStream_t s,
+              std::string *err) {
+    // aux: device scratch for flags (max(w,h)*4 ints) + curve + csum
+    float *src = map, *dst = tmp;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int vertical = pass == 0;
+        const float sd = vertical ? vs : hs;
+        if (!(sd > 0.0f)) continue;
+        std::vector<float> curve, sum;
+        int length;
+        float total;
+        make_rle_curve(sd, curve, sum, length, total);
+        const int lines = vertical ? w : h;
+        int *flags = (int *)aux;
+        float *d_curve = (float *)(aux + (size_t)std::max(w, h) * 4 * sizeof(int));
+        float *d_sum = d_curve + curve.size();
+        if (hipMemcpyAsync(d_curve, curve.data(), curve.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(d_sum, sum.data(), sum.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {      // the host vectors die at the end of this iteration
+            *err = "gaussian_blur: tap upload failed";
+            return -1;
+        }
+        FirArgs g{w, h, vertical, length, total, (int)total};
+        k_fir_same<<<(unsigned)(((long)lines * 4 + 255) / 256), 256, 0, s>>>(src, flags, g);
+        k_fir_apply<<<(unsigned)(((long)w * h * 4 + 255) / 256), 256, 0, s>>>(src, dst, flags, d_curve, d_sum, g);
+        std::swap(src, dst);
+    }
+    if (src != map && hipMemcpyAsync(map, src, (size_t)w * h * 16, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        *err = "gaussian_blur: copy failed";
+        return -1;
+    }
+    (void)ws;
+    return 0;
+}
+
 int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, int rw, int rh, float *out_map,
                   NativeWorkspace &ws, hipStream_t s, std::string *err) {
     const HImage &img = rec.args[0].img;
@@ -285,17 +417,15 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
     float ay = (float)((float)(h - 1) / 2.0);
     ay *= -1.0f;
     float hs = (float)fabs(hdev * ax), vs = (float)fabs(vdev * ay);
-    if (hs < 0.5f || vs < 0.5f) {
-        *err = "gaussian_blur: sigma < 0.5 px (the reference's RLE/FIR path, gauss.c:500-639) is not implemented on the GPU yet";
-        return -1;
-    }
-    // workspace: f64 scan scratch (w*h*4 doubles) followed by the transposed intermediate map
+    // workspace: f64 scan scratch (w*h*4 doubles) followed by the intermediate map
     const size_t scratch_bytes = (size_t)w * h * 4 * sizeof(double);
     const size_t map_bytes = (size_t)w * h * 4 * sizeof(float);
     char *wsp = (char *)ws.reserve(scratch_bytes + map_bytes);
     if (!wsp) { *err = "gaussian_blur: out of device memory for the scan workspace"; return -1; }
     double *scratch = (double *)wsp;
     float *mapT = (float *)(wsp + scratch_bytes);
+    if (hs < 0.5f || vs < 0.5f)     // gauss.c:662-665
+        return gauss_rle(out_map, mapT, w, h, hs, vs, ws, wsp, s, err);
     IirCoef c;
     // vertical pass first (gauss.c:155-201): lines = columns, n = h; result transposed into mapT[w][h][4]
     find_iir_constants(c, vs);

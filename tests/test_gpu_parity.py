@@ -138,23 +138,12 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     inv = flt.invoke(w, h)
     if needs:
         inv.set_image("in", marlene)
-    if name == "gaussian_blur":
-        # the self-test renders with default user values: dev = 0 -> sigma 0 -> the FIR path,
-        # which the GPU backend reports as unsupported through both tiers
-        with pytest.raises(mm.MathMapError):
-            inv.render(t=0.25)
-        want = None
-    else:
-        want = inv.render(t=0.25)
+    want = inv.render(t=0.25)   # gaussian_blur: default dev = 0 -> sigma 0 -> FIR path with both passes skipped
     got = np.zeros((h, w, 4), np.uint8)
     img = np.ascontiguousarray(marlene)
     rc = lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p) if needs else None,
                                             img.shape[1], img.shape[0], 3, w, h, 0.25, bands,
                                             got.ctypes.data_as(C.c_void_p))
-    if name == "gaussian_blur":
-        # default dev = 0 -> sigma 0 -> the FIR path, which the GPU backend reports as unsupported
-        assert rc != 0
-        return
     assert rc == 0, lib().mmhip_selftest_error().decode()
     assert np.array_equal(got, want)
 
@@ -231,3 +220,43 @@ def test_complex_math_float_ulps(expr):
     err = np.hypot(a[..., 0] - b[..., 0], a[..., 1] - b[..., 1]) / mag
     tol = 2e-5 if expr == "gamma(z)" else 4e-6   # |error| relative to |result|, ~ tens of float ulps of slack
     assert np.percentile(err[finite], 99.5) < tol, "%s: p99.5 rel err %.3g" % (expr, np.percentile(err[finite], 99.5))
+
+
+@pytest.mark.parametrize("hdev,vdev", [(0.001, 0.001), (0.0012, 0.04), (0.05, 0.0009), (0.0, 0.02)])
+@pytest.mark.parametrize("flat", [False, True])
+def test_gauss_fir_path_matches_oracle(hdev, vdev, flat):
+    """sigma < 0.5 px on an axis selects the reference's FIR/RLE blur (gauss.c:500-639); a mostly
+    flat image additionally selects its run-length branch (do_encoded_lre) per line."""
+    w, h = 333, 251
+    if flat:
+        img = np.full((h, w, 3), 40, np.uint8)
+        img[100:140, 50:300] = (200, 120, 30)
+        img[:, 170:173] = 255
+    else:
+        img = W.synthetic_image(w, h, seed=9)
+    uv = {"hdev": hdev, "vdev": vdev}
+    flt, got = hip_render(W.GAUSS_DIRECT, w, h, uv, img)
+    want = cpu_render(flt, w, h, uv, img)
+    assert stats(got, want)[0] <= 1
+
+
+@pytest.mark.parametrize("bpp", [1, 2, 3])
+def test_output_bpp_variants(bpp):
+    """output_bpp 1..3 of calc_lines (grey, grey+alpha, RGB; new_template.c.in:279-293)."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = 200, 120
+    img = W.synthetic_image(w, h, seed=2)
+    flt = mm.Filter(W.POND)
+    inv = flt.invoke(w, h)
+    inv.set_image("in", img)
+    dev = lib().mmhip_device_alloc(w * h * bpp)
+    try:
+        inv.render_rows(dev, 0, h, t=0.2, bpp=bpp)
+        inv.sync()
+        got = np.empty((h, w, bpp), np.uint8)
+        assert lib().mmhip_copy_to_host(got.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * bpp) == 0
+    finally:
+        lib().mmhip_device_free(C.c_void_p(dev))
+    want = CpuFilter(flt.ir_json).render(w, h, images={"in": img}, t=0.2, bpp=bpp)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
