@@ -103,6 +103,10 @@ int mmhip_set_sampling_offset(mmhip_invocation *inv, float offset_x, float offse
    invocation's own stream).  Asynchronous. */
 int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
                  int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream);
+/* The CLI's -o: supersampled render of a region (two slices + 1-1-2-1-1 / 6 byte combine,
+   call_invocation, mathmap_common.c:880-927).  Compile the filter with supersampling = 1. */
+int mmhip_render_supersampled(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w,
+                              int region_h, void *out_device, int row_stride, int bpp, void *stream);
 /* Convenience: whole frame to a host RGBA8 buffer (width*height*4 bytes); synchronous. */
 int mmhip_render_host(mmhip_invocation *inv, int frame, float t, uint8_t *out_rgba);
 int mmhip_sync(mmhip_invocation *inv);

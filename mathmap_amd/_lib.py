@@ -55,6 +55,8 @@ SYMBOLS = {
     "mmhip_set_sampling_offset": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
     "mmhip_render": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mmhip_render_supersampled": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mmhip_render_host": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mmhip_sync": (C.c_int, [C.c_void_p]),
     "mmhip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),

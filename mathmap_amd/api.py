@@ -175,6 +175,11 @@ class Invocation:
         self._check(lib().mmhip_render(self._h, frame, t, rx, ry, rw, rh, first_row, last_row, C.c_void_p(out_ptr),
                                        row_stride, bpp, 1 if floatmap else 0, C.c_void_p(stream)))
 
+    def render_supersampled(self, out_ptr, t=0.0, frame=0, bpp=4, stream=0):
+        """The CLI's -o (supersampling) for the whole frame, into device memory at out_ptr."""
+        self._check(lib().mmhip_render_supersampled(self._h, frame, t, 0, 0, self.width, self.height, C.c_void_p(out_ptr),
+                                                    self.width * bpp, bpp, C.c_void_p(stream)))
+
     def sync(self):
         self._check(lib().mmhip_sync(self._h))
 

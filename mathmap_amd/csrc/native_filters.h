@@ -25,4 +25,7 @@ int run_native_filter(const std::string &func, const HNativeRec &rec, const std:
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
                       std::string *err);
 
+void launch_supersample_combine(const unsigned char *longs, const unsigned char *shorts, unsigned char *out, int w, int h,
+                                int bpp, int out_stride, hipStream_t s);
+
 }  // namespace mm

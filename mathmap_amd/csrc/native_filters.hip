@@ -450,6 +450,35 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
 
 }  // namespace
 
+// Supersampling combine of call_invocation (mathmap_common.c:880-927): per output byte
+// (l1[c] + l1[c+1] + 2*l2[c] + l3[c] + l3[c+1]) / 6 in integer arithmetic, where l1/l3 are
+// rows r and r+1 of the "long" slice (width+1, offset -0.5) and l2 row r of the short slice.
+__global__ void __launch_bounds__(256) k_supersample_combine(const unsigned char *__restrict__ longs,
+                                                             const unsigned char *__restrict__ shorts,
+                                                             unsigned char *__restrict__ out, int w, int h, int bpp,
+                                                             int out_stride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)w * h * bpp) return;
+    const int b = (int)(i % bpp);
+    const long px = i / bpp;
+    const int col = (int)(px % w), row = (int)(px / w);
+    const long lstride = (long)(w + 1) * bpp;
+    const unsigned char *l1 = longs + row * lstride;
+    // the reference's last iteration renders no new line3 (calc_lines clips at the slice end),
+    // so line3 still equals line1 there
+    const unsigned char *l3 = longs + (row + 1 < h ? row + 1 : row) * lstride;
+    const unsigned char *l2 = shorts + (long)row * w * bpp;
+    const int v = (l1[col * bpp + b] + l1[(col + 1) * bpp + b] + 2 * l2[col * bpp + b] + l3[col * bpp + b] +
+                   l3[(col + 1) * bpp + b]) / 6;
+    out[(long)row * out_stride + (long)col * bpp + b] = (unsigned char)v;
+}
+
+void launch_supersample_combine(const unsigned char *longs, const unsigned char *shorts, unsigned char *out, int w, int h,
+                                int bpp, int out_stride, hipStream_t s) {
+    const long n = (long)w * h * bpp;
+    k_supersample_combine<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(longs, shorts, out, w, h, bpp, out_stride);
+}
+
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
                       std::string *err) {

@@ -556,6 +556,34 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     return 0;
 }
 
+// call_invocation with supersampling (mathmap_common.c:880-927), whole region on the GPU.
+// The filter must have been compiled with options.supersampling = 1 (nearest fetch without
+// the +0.5, builtins.c:154-158).
+int mmhip_render_supersampled(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w,
+                              int region_h, void *out_device, int row_stride, int bpp, void *stream) {
+    hipStream_t s = stream ? (hipStream_t)stream : inv->stream;
+    const size_t long_bytes = (size_t)(region_w + 1) * bpp * region_h;
+    const size_t short_bytes = (size_t)region_w * bpp * region_h;
+    unsigned char *tmp = (unsigned char *)inv->ws.reserve(long_bytes + short_bytes);
+    if (!tmp) return fail("out of device memory for the supersampling lines");
+    const float ox = inv->sampling_offset_x, oy = inv->sampling_offset_y;
+    // long slice: region_width + 1 columns, offsets -0.5 (invocation_init_slice, :892)
+    inv->sampling_offset_x = -0.5f;
+    inv->sampling_offset_y = -0.5f;
+    int rc = mmhip_render(inv, frame, t, region_x, region_y, region_w + 1, region_h, region_y, region_y + region_h, tmp,
+                          (region_w + 1) * bpp, bpp, 0, s);
+    inv->sampling_offset_x = 0.f;
+    inv->sampling_offset_y = 0.f;
+    if (rc == 0)
+        rc = mmhip_render(inv, frame, t, region_x, region_y, region_w, region_h, region_y, region_y + region_h,
+                          tmp + long_bytes, region_w * bpp, bpp, 0, s);
+    inv->sampling_offset_x = ox;
+    inv->sampling_offset_y = oy;
+    if (rc != 0) return rc;
+    launch_supersample_combine(tmp, tmp + long_bytes, (unsigned char *)out_device, region_w, region_h, bpp, row_stride, s);
+    return 0;
+}
+
 int mmhip_sync(mmhip_invocation *inv) {
     HIP_TRY(hipStreamSynchronize(inv->stream));
     return 0;

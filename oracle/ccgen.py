@@ -364,7 +364,8 @@ class CpuFilter:
         self.lib.mmo_free_memo.argtypes = [C.POINTER(_Args), C.c_int]
 
     def render(self, width, height, uservals=None, images=None, t=0.0, frame=0, intersample=True, threads=1,
-               bpp=4, floatmap=False, edge=(0, 0), edge_colors=(0, 0), rows=None, timing=None):
+               bpp=4, floatmap=False, edge=(0, 0), edge_colors=(0, 0), rows=None, timing=None,
+               region_width=None, sampling_offset=(0.0, 0.0), supersampling=False):
         """Renders on the CPU.  `uservals`: {name: value}; `images`: {name: uint8 [H,W,3|4]}.
         `threads` > 1 splits the rows into contiguous bands like call_invocation_parallel
         (mathmap_common.c:972-1006).  Returns uint8 [H,W,bpp] or float32 [H,W,4]."""
@@ -432,16 +433,18 @@ class CpuFilter:
         a.img_height = a.render_height = a.frame_render_height = height
         a.t, a.frame, a.R = t, frame, np.float32(np.sqrt(2.0))
         a.region_x = a.region_y = 0
-        a.region_width, a.region_height = width, height
-        a.output_bpp, a.row_stride, a.floatmap = bpp, width * bpp, 1 if floatmap else 0
-        a.intersample, a.supersampling = 1 if intersample else 0, 0
+        rw = region_width or width
+        a.region_width, a.region_height = rw, height
+        a.sampling_offset_x, a.sampling_offset_y = sampling_offset
+        a.output_bpp, a.row_stride, a.floatmap = bpp, rw * bpp, 1 if floatmap else 0
+        a.intersample, a.supersampling = 1 if intersample else 0, 1 if supersampling else 0
         a.edge_behaviour_x, a.edge_behaviour_y = edge
         a.edge_color_x, a.edge_color_y = edge_colors
         a.uservals, a.images, a.num_images, a.native_slot_base, a.memo = uv, dtab, len(descs), nbase, memo
         ctab = np.ascontiguousarray(np.concatenate(curves).astype(np.float32)) if curves else np.zeros(1, np.float32)
         gtab = np.ascontiguousarray(np.concatenate(grads).astype(np.uint32)) if grads else np.zeros(1, np.uint32)
         a.curves, a.gradients = ctab.ctypes.data, gtab.ctypes.data
-        out = np.zeros((height, width, 4), np.float32) if floatmap else np.zeros((height, width, bpp), np.uint8)
+        out = np.zeros((height, rw, 4), np.float32) if floatmap else np.zeros((height, rw, bpp), np.uint8)
         xy = C.create_string_buffer(max(self.lib.mmo_xy_size(), 16))
         r0, r1 = rows if rows is not None else (0, height)
         t0 = time.perf_counter()
@@ -467,3 +470,13 @@ class CpuFilter:
         self.lib.mmo_free_memo(C.byref(a), self.nnative)
         del keep
         return out
+
+
+def render_supersampled(cf, width, height, **kw):
+    """call_invocation's supersampling branch (mathmap_common.c:880-927) on top of CpuFilter."""
+    longs = cf.render(width, height, region_width=width + 1, sampling_offset=(-0.5, -0.5), supersampling=True, **kw).astype(np.int32)
+    shorts = cf.render(width, height, supersampling=True, **kw).astype(np.int32)
+    l1 = longs
+    l3 = np.concatenate([longs[1:], longs[-1:]], axis=0)   # the last line3 is never re-rendered
+    out = (l1[:, :-1] + l1[:, 1:] + 2 * shorts + l3[:, :-1] + l3[:, 1:]) // 6
+    return out.astype(np.uint8)

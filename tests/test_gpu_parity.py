@@ -260,3 +260,53 @@ def test_output_bpp_variants(bpp):
         lib().mmhip_device_free(C.c_void_p(dev))
     want = CpuFilter(flt.ir_json).render(w, h, images={"in": img}, t=0.2, bpp=bpp)
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("intersample", [False, True])
+def test_supersampling_matches_oracle(intersample):
+    """-o: two slices (offset 0 and -0.5, the long one a column wider) combined 1-1-2-1-1 / 6."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    from oracle.ccgen import render_supersampled
+    w, h = 211, 157
+    img = W.synthetic_image(w, h, seed=4)
+    flt = mm.Filter(W.POND, intersample=intersample, supersampling=True)
+    inv = flt.invoke(w, h)
+    inv.set_image("in", img)
+    dev = lib().mmhip_device_alloc(w * h * 4)
+    try:
+        inv.render_supersampled(dev, t=0.3)
+        inv.sync()
+        got = np.empty((h, w, 4), np.uint8)
+        assert lib().mmhip_copy_to_host(got.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * 4) == 0
+    finally:
+        lib().mmhip_device_free(C.c_void_p(dev))
+    want = render_supersampled(CpuFilter(flt.ir_json), w, h, images={"in": img}, t=0.3, intersample=intersample)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_command_line_reproduces_golden(tmp_path, marlene):
+    """The `mathmap` command line (mathmap_hip_cli): -i -f script -Din=png out.png, as the
+    reference's tests/run_tests.sh invokes it; PNG decode/encode through the bundled codec."""
+    import subprocess
+    from PIL import Image
+    from tests.conftest import GOLDEN, ROOT
+    import os
+    cli = os.path.join(ROOT, "mathmap_amd", "mathmap_hip_cli")
+    script = tmp_path / "pond.mm"
+    script.write_text(W.POND)
+    out = tmp_path / "out.png"
+    r = subprocess.run([cli, "-i", "-f", str(script), "-Din=" + os.path.join(GOLDEN, "marlene.png"), str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    got = np.array(Image.open(out))
+    assert got.shape == (256, 256, 3)
+    assert np.abs(got.astype(int) - load_png_rgb("distorts_pond.png").astype(int)).max() <= 1
+    # render test with -s and -D for a scalar user value
+    script2 = tmp_path / "mandel.mm"
+    script2.write_text(W.MANDELBROT)
+    out2 = tmp_path / "m.png"
+    r = subprocess.run([cli, "-i", "-s", "256x256", "-f", str(script2), str(out2)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert np.array_equal(np.array(Image.open(out2)), load_png_rgb("render_mandelbrot.png"))
