@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="frame edge in pixels (default 8192; 16384 for gauss)")
     ap.add_argument("--tile-w", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--specialize", type=int, default=1,
+                    help="1 = user-value specialising JIT (default), 0 = generic kernel reading user values at run time")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
     args = ap.parse_args()
 
@@ -48,7 +50,7 @@ def main():
 
     w = h = args.size or (16384 if args.workload == "gauss" else 8192)
     src = W.ALL["gauss_direct" if args.workload == "gauss" else args.workload]
-    flt = mm.Filter(src, tile_w=args.tile_w)
+    flt = mm.Filter(src, tile_w=args.tile_w, specialize=bool(args.specialize))
     t0 = time.perf_counter()
     inv = flt.invoke(w, h)
     jit_s = time.perf_counter() - t0

@@ -43,7 +43,10 @@ typedef struct mmhip_options {
     int supersampling;    /* affects the nearest fetch only (builtins.c:154-158) */
     int edge_behaviour_x, edge_behaviour_y;
     int tile_w;           /* workgroup tile width in pixels: 8,16,32,64,128,256 (0 = default) */
-    int reserved[8];
+    int specialize_uservals; /* 1 = JIT a kernel variant per set of scalar user values with the values baked
+                                in as literals and the reference's literal folds applied (x*0 -> 0, x+0 -> x,
+                                dead branches); off by default */
+    int reserved[7];
 } mmhip_options;
 
 typedef struct mmhip_userval_info {
@@ -62,6 +65,9 @@ const char *mmhip_version(void);
 /* ---- compile (no GPU needed up to mmhip_filter_load) ---- */
 void mmhip_default_options(mmhip_options *o);
 mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts);
+/* like mmhip_compile, with n scalar user values (index, value) baked in as literals */
+mmhip_filter *mmhip_compile_specialized(const char *source, const mmhip_options *opts, int n, const int *indices,
+                                        const double *values);
 void mmhip_filter_free(mmhip_filter *f);
 const char *mmhip_filter_name(const mmhip_filter *f);
 int mmhip_filter_num_uservals(const mmhip_filter *f);

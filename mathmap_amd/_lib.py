@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmathmap_hip.so")
 class Options(C.Structure):
     _fields_ = [("intersample", C.c_int), ("supersampling", C.c_int),
                 ("edge_behaviour_x", C.c_int), ("edge_behaviour_y", C.c_int),
-                ("tile_w", C.c_int), ("reserved", C.c_int * 8)]
+                ("tile_w", C.c_int), ("specialize_uservals", C.c_int), ("reserved", C.c_int * 7)]
 
 
 class UservalInfo(C.Structure):
@@ -30,6 +30,8 @@ SYMBOLS = {
     "mmhip_version": (C.c_char_p, []),
     "mmhip_default_options": (None, [C.POINTER(Options)]),
     "mmhip_compile": (C.c_void_p, [C.c_char_p, C.POINTER(Options)]),
+    "mmhip_compile_specialized": (C.c_void_p, [C.c_char_p, C.POINTER(Options), C.c_int, C.POINTER(C.c_int),
+                                               C.POINTER(C.c_double)]),
     "mmhip_filter_free": (None, [C.c_void_p]),
     "mmhip_filter_name": (C.c_char_p, [C.c_void_p]),
     "mmhip_filter_num_uservals": (C.c_int, [C.c_void_p]),

@@ -29,14 +29,30 @@ class Filter:
     """A compiled .mm filter (front-end + IR + generated HIP kernel string)."""
 
     def __init__(self, source, intersample=True, supersampling=False, edge_x=EDGE_COLOR, edge_y=EDGE_COLOR,
-                 tile_w=0):
+                 tile_w=0, specialize=False, constants=None):
         o = Options()
         lib().mmhip_default_options(C.byref(o))
         o.intersample = 1 if intersample else 0
         o.supersampling = 1 if supersampling else 0
         o.edge_behaviour_x, o.edge_behaviour_y = edge_x, edge_y
         o.tile_w = tile_w
-        self._h = lib().mmhip_compile(source.encode(), C.byref(o))
+        o.specialize_uservals = 1 if specialize else 0
+        if constants:
+            # bake scalar user values in as literals (the variant the specialising JIT builds lazily)
+            probe = lib().mmhip_compile(source.encode(), C.byref(o))
+            if not probe:
+                raise MathMapError(_err())
+            names = {}
+            for i in range(lib().mmhip_filter_num_uservals(probe)):
+                info = UservalInfo()
+                lib().mmhip_filter_userval_info(probe, i, C.byref(info))
+                names[info.name.decode()] = i
+            lib().mmhip_filter_free(probe)
+            idx = (C.c_int * len(constants))(*[names[k] for k in constants])
+            val = (C.c_double * len(constants))(*[float(v) for v in constants.values()])
+            self._h = lib().mmhip_compile_specialized(source.encode(), C.byref(o), len(constants), idx, val)
+        else:
+            self._h = lib().mmhip_compile(source.encode(), C.byref(o))
         if not self._h:
             raise MathMapError(_err())
 

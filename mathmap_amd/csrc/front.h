@@ -122,6 +122,8 @@ void register_builtins(Module &m);   // builtins.cpp
 void parse_module(Module &m, const std::string &source);
 
 // Lowers filter `f` (with all callees inlined) to IR.  lower.cpp
-std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f);
+// `uv_consts` (optional): user-value index -> literal to bake in instead of the run-time
+// USERVAL_*_ACCESS read (user-value specialisation, specialize.cpp).
+std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<int, Primary> *uv_consts = nullptr);
 
 }  // namespace mm

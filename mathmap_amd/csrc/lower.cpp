@@ -36,6 +36,7 @@ struct ImageChain {
 class Lowerer {
    public:
     Lowerer(Module &m, FilterCode &code) : m_(m), code_(code), g_(code) {}
+    const std::map<int, Primary> *uv_consts_ = nullptr;
     void run(Filter *f);
 
    private:
@@ -227,7 +228,11 @@ void Lowerer::gen_filter(Filter *f, const std::vector<Primary> *args, CompVar *r
                 env.uservals[u.index] = g_.assign(bv, Rhs::V(rz));
             } else {
                 CompVar *bv = g_.temp(ty);
-                env.uservals[u.index] = g_.assign_op(bv, getters[(int)u.kind], {Primary::I(u.index)});
+                auto cit = uv_consts_ ? uv_consts_->find(u.index) : std::map<int, Primary>::const_iterator();
+                if (uv_consts_ && cit != uv_consts_->end() && (u.kind == UvKind::Int || u.kind == UvKind::Float || u.kind == UvKind::Bool))
+                    env.uservals[u.index] = g_.assign(bv, Rhs::P(cit->second));
+                else
+                    env.uservals[u.index] = g_.assign_op(bv, getters[(int)u.kind], {Primary::I(u.index)});
             }
         }
         if (needs_xy_scaling(f->flags)) gen_xy_bindings(internal_value("x", false), internal_value("y", false));
@@ -497,11 +502,12 @@ void Lowerer::run(Filter *f) {
 
 }  // namespace
 
-std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f) {
+std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<int, Primary> *uv_consts) {
     if (f->kind != Filter::MathMap) throw CompileError("cannot lower a native filter");
     std::unique_ptr<FilterCode> code(new FilterCode());
     code->filter = f;
     Lowerer l(m, *code);
+    l.uv_consts_ = uv_consts;
     l.run(f);
     propagate_types(*code);
     return code;

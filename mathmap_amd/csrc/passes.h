@@ -7,4 +7,5 @@ bool copy_propagate(FilterCode &code);
 bool eliminate_dead_code(FilterCode &code);
 void optimize(FilterCode &code);
 void analyze_frame_constants(FilterCode &code);
+void specialize_constants(FilterCode &code);   // specialize.cpp
 }  // namespace mm

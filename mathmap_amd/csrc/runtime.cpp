@@ -65,11 +65,12 @@ void mmhip_default_options(mmhip_options *o) {
     o->tile_w = 0;
 }
 
-mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts) {
+static mmhip_filter *compile_source(const char *source, const mmhip_options *opts, const std::map<int, Primary> *consts) {
     std::unique_ptr<mmhip_filter> f(new mmhip_filter());
     try {
         parse_module(f->module, source);
-        f->code = lower_filter(f->module, f->module.main);
+        f->code = lower_filter(f->module, f->module.main, consts);
+        if (consts) specialize_constants(*f->code);
         optimize(*f->code);
         analyze_frame_constants(*f->code);
         KernelOptions ko;
@@ -79,7 +80,10 @@ mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts) {
             ko.edge_x = opts->edge_behaviour_x;
             ko.edge_y = opts->edge_behaviour_y;
             if (opts->tile_w) ko.tile_w = opts->tile_w;
+            f->opts = *opts;
+            f->specialize = opts->specialize_uservals != 0;
         }
+        f->source = source;
         f->kopt = ko;
         f->ir_json = dump_ir(*f->code);
         f->ks = generate_hip(*f->code, ko);
@@ -92,6 +96,30 @@ mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts) {
         return nullptr;
     }
     return f.release();
+}
+
+mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts) { return compile_source(source, opts, nullptr); }
+
+// Compiles with the given scalar user values (index, value) baked in as literals -- the same
+// variant active_filter() builds lazily; exposed so the specialised kernel can be inspected
+// and tested without a GPU.  Values of int/bool user values are truncated to int.
+mmhip_filter *mmhip_compile_specialized(const char *source, const mmhip_options *opts, int n, const int *indices,
+                                        const double *values) {
+    Module probe;
+    try {
+        parse_module(probe, source);
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+    std::map<int, Primary> consts;
+    for (int i = 0; i < n; ++i) {
+        if (indices[i] < 0 || indices[i] >= (int)probe.main->uservals.size()) { g_err = "user value index out of range"; return nullptr; }
+        const UservalInfo &u = probe.main->uservals[indices[i]];
+        if (u.kind == UvKind::Float) consts[u.index] = Primary::F((float)values[i]);
+        else if (u.kind == UvKind::Int || u.kind == UvKind::Bool) consts[u.index] = Primary::I((int)values[i]);
+    }
+    return compile_source(source, opts, &consts);
 }
 
 }  // extern "C"
@@ -118,6 +146,7 @@ extern "C" {
 
 void mmhip_filter_free(mmhip_filter *f) {
     if (!f) return;
+    for (auto &p : f->spec_cache) mmhip_filter_free(p.second);
     if (f->mod) (void)hipModuleUnload(f->mod);
     delete f;
 }
@@ -262,6 +291,7 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
     if (!inv->curves.empty() && (e = hipMalloc((void **)&inv->d_curves, inv->curves.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
     if (!inv->gradients.empty() && (e = hipMalloc((void **)&inv->d_gradients, inv->gradients.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(inv->d_xy, 0, f->ks.xy_bytes)) != hipSuccess) return bail("hipMemset", e);
+    inv->xy_cap = f->ks.xy_bytes;
     return inv.release();
 }
 
@@ -480,9 +510,35 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
     return 0;
 }
 
+// The kernel set to launch: the generic filter, or -- with options.specialize_uservals -- a
+// variant with the current scalar user values baked in as literals (built on first use per
+// value set, cached on the filter and on disk through the hiprtc cache).
+static mmhip_filter *active_filter(mmhip_invocation *inv) {
+    mmhip_filter *f = inv->f;
+    if (!f->specialize || !f->ks.natives.empty() || f->source.empty()) return f;
+    const auto &uvs = f->module.main->uservals;
+    std::string key;
+    std::map<int, Primary> consts;
+    for (const UservalInfo &u : uvs) {
+        if (u.kind == UvKind::Int || u.kind == UvKind::Bool) consts[u.index] = Primary::I(inv->uv[u.index].i);
+        else if (u.kind == UvKind::Float) consts[u.index] = Primary::F(inv->uv[u.index].f);
+        else continue;
+        key.append((const char *)&inv->uv[u.index], sizeof(HUserval));
+    }
+    if (consts.empty()) return f;
+    auto it = f->spec_cache.find(key);
+    if (it != f->spec_cache.end()) return it->second ? it->second : f;
+    mmhip_options o = f->opts;
+    o.specialize_uservals = 0;
+    mmhip_filter *sp = compile_source(f->source.c_str(), &o, &consts);
+    if (sp && mmhip_filter_jit(sp, 1) < 0) { mmhip_filter_free(sp); sp = nullptr; }
+    f->spec_cache[key] = sp;          // nullptr = fall back to the generic kernel for this value set
+    return sp ? sp : f;
+}
+
 int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
                  int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream) {
-    mmhip_filter *f = inv->f;
+    mmhip_filter *f = active_filter(inv);
     hipStream_t s = stream ? (hipStream_t)stream : inv->stream;
     if (bpp < 1 || bpp > 4) return fail("output_bpp must be 1..4");
     if (region_w <= 0 || region_h <= 0) return fail("empty region");
@@ -536,6 +592,12 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     a.xtab = inv->d_xtab;
     a.ytab = inv->d_ytab;
 
+    if (f->ks.xy_bytes > inv->xy_cap) {
+        if (inv->d_xy) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(inv->d_xy); }
+        HIP_TRY(hipMalloc((void **)&inv->d_xy, f->ks.xy_bytes));
+        HIP_TRY(hipMemset(inv->d_xy, 0, f->ks.xy_bytes));
+        inv->xy_cap = f->ks.xy_bytes;
+    }
     char *xy = inv->d_xy;
     void *params[] = {&a, &xy};
     {

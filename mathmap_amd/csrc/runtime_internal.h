@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -23,6 +24,12 @@ struct mmhip_filter {
     hipFunction_t f_pro = nullptr, f_pix = nullptr;
     bool loaded = false;
     double jit_seconds = 0;
+    // user-value specialisation (specialize.cpp): kernels with the scalar user values baked in,
+    // keyed by the value bytes; owned by this filter
+    std::string source;
+    mmhip_options opts{};
+    bool specialize = false;
+    std::map<std::string, mmhip_filter *> spec_cache;
 };
 
 struct mmhip_invocation {
@@ -45,6 +52,7 @@ struct mmhip_invocation {
     std::vector<unsigned long long> native_memo_gen;
     unsigned long long input_generation = 1;
     char *d_xy = nullptr;
+    int xy_cap = 0;
     float *d_xtab = nullptr, *d_ytab = nullptr;   // per-column / per-row coordinates of the current launch
     int xtab_cap = 0, ytab_cap = 0;
     hipStream_t stream = nullptr;

@@ -310,3 +310,36 @@ def test_command_line_reproduces_golden(tmp_path, marlene):
                        stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     assert np.array_equal(np.array(Image.open(out2)), load_png_rgb("render_mandelbrot.png"))
+
+
+@pytest.mark.parametrize("name,uv", [
+    ("mandelbrot", {}), ("mandelbrot", {"num_iterations": 77, "pj": 0.25}), ("mandelbrot", {"ci": 0.3, "ck": -0.4}),
+    ("droste", {}), ("droste", {"NoTransparency": 1, "Zoom": 3}), ("droste", {"ShowGrid": 1, "ShowFrame": 1, "Untwist": 1}),
+    ("pond", {"height": 0.0}), ("pond", {"wavelength": 0.0}), ("closure_call", {"radius": 0.0}),
+])
+def test_userval_specialisation_is_bit_identical(name, uv):
+    """The specialising JIT (scalar user values baked in, reference-style literal folds,
+    optimistic constant propagation through loop phis) must not change a single byte."""
+    w, h = 400, 300
+    src = W.ALL[name]
+    img = W.synthetic_image(w, h, seed=6) if "image in" in src else None
+    _, generic = hip_render(src, w, h, uv, img, t=0.4)
+    _, special = hip_render(src, w, h, uv, img, t=0.4, specialize=True)
+    assert np.array_equal(generic, special)
+    flt = mm.Filter(src, specialize=True)
+    # changing a user value after the first render must re-specialise
+    inv = flt.invoke(w, h)
+    if img is not None:
+        inv.set_image("in", img)
+    first = inv.render(t=0.4)
+    for k, v in uv.items():
+        inv.set(k, v)
+    assert np.array_equal(inv.render(t=0.4), special)
+    assert first.shape == special.shape
+
+
+def test_specialised_mandelbrot_8192_equals_generic():
+    w = h = 8192
+    a = mm.Filter(W.MANDELBROT).invoke(w, h).render()
+    b = mm.Filter(W.MANDELBROT, specialize=True).invoke(w, h).render()
+    assert np.array_equal(a, b)
