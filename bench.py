@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="frame edge in pixels (default 8192; 16384 for gauss)")
     ap.add_argument("--tile-w", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-generic", action="store_true", help="skip the generic-kernel comparison (for profiling runs)")
     ap.add_argument("--specialize", type=int, default=1,
                     help="1 = user-value specialising JIT (default), 0 = generic kernel reading user values at run time")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
@@ -140,6 +141,35 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mm_pixels", "kernel_ms": k_ms, "algorithmic_bytes_per_pixel": bpp},
         }
+        if args.workload == "mandelbrot":
+            # compute-side view (the kernel writes 4 B/px and reads nothing, so HBM is not its
+            # bound): iterations are recovered exactly from the grey level n/32
+            n_iter = torch.round(out[:, :, 0].to(torch.float32) * (32.0 / 255.0)).sum().item()
+            flops = n_iter * 10.0     # per iteration: 5 mul + 5 add/sub on the complex plane (j,k parts are 0)
+            res["valu"] = {"pixel_iterations_per_launch": n_iter, "useful_flops_per_launch": flops,
+                           "achieved_tflops": flops / (k_ms * 1e-3) / 1e12, "peak_tflops_f32_no_fma": 78.6,
+                           "note": "exact-rounding code cannot use FMA, so the peak is half the 157.3 TF vector peak"}
+        if world == 1 and args.specialize and not args.no_generic:
+            # the generic kernel (user values read at run time) on the same frame: must be
+            # byte-identical; its rate is reported beside the specialised one
+            g_flt = mm.Filter(src, tile_w=args.tile_w, specialize=False)
+            g_inv = g_flt.invoke(w, h)
+            if needs_image:
+                g_inv.set_image_device("in", dev_img.data_ptr(), w, h, keepalive=dev_img)
+            if args.workload == "gauss":
+                g_inv.set("hdev", sigma)
+                g_inv.set("vdev", sigma)
+            g_out = torch.empty_like(out)
+            g_inv.enable_timing(True)
+            gms = []
+            step(args.steps - 1)     # re-render the last timed frame for the comparison
+            torch.cuda.synchronize()
+            for i in range(3):
+                g_inv.render_rows(g_out.data_ptr(), 0, h, t=(((args.steps - 1) * world + rank) % 120) / 120.0, stream=stream)
+                gms.append(g_inv.last_kernel_ms())
+            torch.cuda.synchronize()
+            res["generic_kernel"] = {"kernel_ms": float(np.mean(gms[1:])), "value": w * h / 1e6 / (float(np.mean(gms[1:])) * 1e-3),
+                                     "byte_identical_to_specialised": bool(torch.equal(g_out, out))}
         if not args.no_cpu_baseline and world == 1:
             from oracle.ccgen import CpuFilter
             cf = CpuFilter(flt.ir_json)
