@@ -68,6 +68,8 @@ mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts);
 /* like mmhip_compile, with n scalar user values (index, value) baked in as literals */
 mmhip_filter *mmhip_compile_specialized(const char *source, const mmhip_options *opts, int n, const int *indices,
                                         const double *values);
+/* builds a filter from an IR dump (the JSON of mmhip_filter_ir_json): IR-level entry point */
+mmhip_filter *mmhip_compile_ir_json(const char *ir_json, const mmhip_options *opts);
 void mmhip_filter_free(mmhip_filter *f);
 const char *mmhip_filter_name(const mmhip_filter *f);
 int mmhip_filter_num_uservals(const mmhip_filter *f);

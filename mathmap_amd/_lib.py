@@ -32,6 +32,7 @@ SYMBOLS = {
     "mmhip_compile": (C.c_void_p, [C.c_char_p, C.POINTER(Options)]),
     "mmhip_compile_specialized": (C.c_void_p, [C.c_char_p, C.POINTER(Options), C.c_int, C.POINTER(C.c_int),
                                                C.POINTER(C.c_double)]),
+    "mmhip_compile_ir_json": (C.c_void_p, [C.c_char_p, C.POINTER(Options)]),
     "mmhip_filter_free": (None, [C.c_void_p]),
     "mmhip_filter_name": (C.c_char_p, [C.c_void_p]),
     "mmhip_filter_num_uservals": (C.c_int, [C.c_void_p]),

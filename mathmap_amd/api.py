@@ -29,7 +29,7 @@ class Filter:
     """A compiled .mm filter (front-end + IR + generated HIP kernel string)."""
 
     def __init__(self, source, intersample=True, supersampling=False, edge_x=EDGE_COLOR, edge_y=EDGE_COLOR,
-                 tile_w=0, specialize=False, constants=None):
+                 tile_w=0, specialize=False, constants=None, ir_json=None):
         o = Options()
         lib().mmhip_default_options(C.byref(o))
         o.intersample = 1 if intersample else 0
@@ -37,7 +37,9 @@ class Filter:
         o.edge_behaviour_x, o.edge_behaviour_y = edge_x, edge_y
         o.tile_w = tile_w
         o.specialize_uservals = 1 if specialize else 0
-        if constants:
+        if ir_json is not None:
+            self._h = lib().mmhip_compile_ir_json(ir_json.encode(), C.byref(o))
+        elif constants:
             # bake scalar user values in as literals (the variant the specialising JIT builds lazily)
             probe = lib().mmhip_compile(source.encode(), C.byref(o))
             if not probe:

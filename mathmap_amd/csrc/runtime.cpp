@@ -30,9 +30,10 @@
 
 using namespace mm;
 
-namespace {
+thread_local std::string g_mmhip_err;
+#define g_err g_mmhip_err
 
-thread_local std::string g_err;
+namespace {
 
 int fail(const std::string &msg) {
     g_err = msg;

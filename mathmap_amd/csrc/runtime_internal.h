@@ -65,6 +65,8 @@ struct mmhip_invocation {
 };
 
 
+extern thread_local std::string g_mmhip_err;   // message behind mmhip_last_error()
+
 // Two-step construction from already lowered IR (used by the reference-ABI importer):
 // create, fill f->module (filters, main) and f->code, then finalize (passes + codegen).
 mmhip_filter *mmhip_filter_new_empty();

@@ -86,6 +86,8 @@ def _run_tests_cases():
             continue
         kind, script, golden, rest = m.groups()
         script = script.strip('"')
+        if script == "()":      # the shell function definitions themselves
+            continue
         uv = {k: float(v) for k, v in re.findall(r"-D(\w+)=([-\d.]+)", rest)}
         cases.append((script, golden, uv, kind == "modify"))
     return cases
@@ -96,7 +98,7 @@ def test_oracle_sweep_over_reference_suite(marlene):
     """Every case of the reference's run_tests.sh that our front-end + oracle support must
     match its golden within 1 LSB (discontinuous filters: <0.1% of values further off)."""
     cases = _run_tests_cases()
-    assert len(cases) >= 70
+    assert len(cases) == 80
     results = {}
     for script, golden, uv, needs in cases:
         p = os.path.join(REFERENCE, "tests", script)

@@ -343,3 +343,40 @@ def test_specialised_mandelbrot_8192_equals_generic():
     a = mm.Filter(W.MANDELBROT).invoke(w, h).render()
     b = mm.Filter(W.MANDELBROT, specialize=True).invoke(w, h).render()
     assert np.array_equal(a, b)
+
+
+def _ir_manifest():
+    import json
+    import os
+    from tests.conftest import GOLDEN
+    p = os.path.join(GOLDEN, "ir", "manifest.json")
+    return json.load(open(p)) if os.path.exists(p) else []
+
+
+@pytest.mark.parametrize("case", _ir_manifest(), ids=lambda c: c["golden"])
+def test_reference_suite_on_gpu(case, marlene):
+    """Every filter of the reference's tests/run_tests.sh that compiles (IR fixtures made by
+    tests/make_ir_fixtures.py), rendered on the GPU like the suite does (-i, 256x256 or
+    -Din=marlene.png) and compared with the reference's golden PNG.  <= 1 LSB; filters with
+    discontinuities may flip < 0.1 % of the values where OCML and glibc differ by a float ulp."""
+    import gzip
+    import os
+    from tests.conftest import GOLDEN
+    ir = gzip.open(os.path.join(GOLDEN, "ir", case["ir"]), "rt").read()
+    flt = mm.Filter("", ir_json=ir)
+    inv = flt.invoke(256, 256)
+    for k, v in case["uservals"].items():
+        inv.set(k, v)
+    if case["needs_image"]:
+        for u in flt.uservals:
+            if u["kind"] == mm.api.UV_IMAGE:
+                inv.set_image(u["name"], marlene)
+    try:
+        got = inv.render()
+    except mm.MathMapError as e:
+        if "not implemented" in str(e):
+            pytest.skip(str(e))
+        raise
+    want = load_png_rgb(case["golden"])
+    mx, nd, n1 = stats(got[:, :, :3], want)
+    assert mx <= 1 or n1 < 0.001 * want.size, "%s: max %d, %d differ, %d by more than 1" % (case["golden"], mx, nd, n1)
