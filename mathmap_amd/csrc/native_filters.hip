@@ -483,6 +483,23 @@ int run_native_filter(const std::string &func, const HNativeRec &rec, const std:
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
                       std::string *err) {
     if (func == "native_filter_gaussian_blur") return gaussian_blur(rec, images, render_w, render_h, out_map, ws, stream, err);
+    if (func == "RENDER") {   // render_image (builtins.c:267-346), drawable / float-map branches
+        const HImage &img = rec.args[0].img;
+        if (img.idx < 0 || img.idx >= (int)images.size()) { *err = "render(): rendering a filter closure is not supported by the HIP backend yet"; return -1; }
+        const HImageDesc &in = images[img.idx];
+        const int w = render_w, h = render_h;
+        if (in.kind == IMG_FLOATMAP) {
+            if (in.w != w || in.h != h) { *err = "render(): float-map input of a different size"; return -1; }
+            if (hipMemcpyAsync(out_map, in.data, (size_t)w * h * 16, hipMemcpyDeviceToDevice, stream) != hipSuccess) { *err = "render(): copy failed"; return -1; }
+            return 0;
+        }
+        if (in.kind != IMG_DRAWABLE) { *err = "render(): input image is not bound"; return -1; }
+        const long n = (long)w * h;
+        k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(
+            (const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y, in.middle_x, in.middle_y, img.resized, img.xf,
+            img.yf, 0u, 0u, 0, (float4 *)out_map, w, h);
+        return 0;
+    }
     *err = "native filter " + func + " is not implemented in the HIP backend yet";
     return -1;
 }
