@@ -222,6 +222,15 @@ struct Generator {
         }
     }
 
+    static bool uses_noise(const Block &b) {
+        for (const Stmt *s : b) {
+            if ((s->kind == Stmt::Assign) && s->rhs.kind == Rhs::Op && !strncmp(s->rhs.op->cname, "libnoise_", 9)) return true;
+            if (s->kind == Stmt::If && (uses_noise(s->then_) || uses_noise(s->else_))) return true;
+            if (s->kind == Stmt::While && uses_noise(s->body)) return true;
+        }
+        return false;
+    }
+
     void find_natives(Block &b) {
         for (Stmt *s : b) {
             if (s->kind == Stmt::Assign) {
@@ -365,6 +374,12 @@ struct Generator {
         out << "#define MM_EDGE_X " << opt.edge_x << "\n#define MM_EDGE_Y " << opt.edge_y << "\n";
         out << "#define MM_TILE_W " << ks.tile_w << "\n#define MM_TILE_H " << ks.tile_h << "\n";
         out << device_prelude() << "\n";
+        if (uses_noise(code.body)) {
+            if (!noise_table_text())
+                throw CompileError("the noise builtins need libnoise's gradient table, which was not available when this "
+                                   "library was built (see tools/extract_noise_table.py)");
+            out << noise_table_text() << device_noise_prelude() << "\n";
+        }
         out << R"(
 MM_DEV mm_image mm_closure_image(const mm_args &A) {
     mm_image im; im.idx = -1; im.pw = A.img_width; im.ph = A.img_height; im.xf = im.yf = 1.0f; im.resized = 0; return im;

@@ -35,7 +35,9 @@ CTYPES = {"int": "int", "float": "float", "complex": "float _Complex", "color": 
 UNSUPPORTED = {"RAND", "ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P", "ELL_INT_D",
                "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ", "ELL_JAC", "SOLVE_LINEAR_2",
                "SOLVE_LINEAR_3", "SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH",
-               "libnoise_perlin", "libnoise_billow", "libnoise_ridged_multi", "libnoise_voronoi"}
+               }
+NOISE_OPS = {"libnoise_perlin", "libnoise_billow", "libnoise_ridged_multi", "libnoise_voronoi"}
+NOISE_LIB = os.path.join(HERE, "_ref", "libmmnoise.so")
 
 
 class OracleUnsupported(Exception):
@@ -58,6 +60,7 @@ class Gen:
     def __init__(self, ir):
         self.ir = ir
         self.vars = {v["id"]: v for v in ir["vars"]}
+        self.uses_noise = False
         self.natives = {}      # id(stmt) -> slot
         self.nnative = 0
         self._find_natives(ir["body"])
@@ -128,6 +131,10 @@ class Gen:
             op = r["op"]
             if op in UNSUPPORTED:
                 raise OracleUnsupported("op %s" % op)
+            if op in NOISE_OPS:
+                if not os.path.exists(NOISE_LIB):
+                    raise OracleUnsupported("op %s (oracle/_ref/libmmnoise.so not built: no reference tree)" % op)
+                self.uses_noise = True
             if op == "RENDER":
                 return "mmo_render(A, %d, %s)" % (self.natives[id(stmt)], ", ".join(self.prim(a) for a in r["args"]))
             return "%s(%s)" % (op, ",".join(self.prim(a) for a in r["args"]))
@@ -234,7 +241,11 @@ class Gen:
         for d in pro_defs:
             if d in pix_uses and d not in pix_def_set and d not in transfers:
                 transfers.append(d)
-        out = ['#include "mm_oracle.h"', "", "typedef struct {"]
+        out = ['#include "mm_oracle.h"',
+               "float libnoise_perlin(int, float, float, float, float, float);",
+               "float libnoise_billow(int, float, float, float, float, float);",
+               "float libnoise_ridged_multi(int, float, float, float, float);",
+               "float libnoise_voronoi(float, float, float, float);", "", "typedef struct {"]
         for d in transfers:
             out.append("  %s %s;" % (self.ctype(d[0]), self.vname(*d)))
         out.append("  int unused_;")
@@ -345,6 +356,7 @@ class CpuFilter:
         gen = Gen(self.ir)
         self.source = gen.source()
         self.nnative = gen.nnative
+        noise = [NOISE_LIB, "-Wl,-rpath," + os.path.dirname(NOISE_LIB)] if gen.uses_noise else []
         key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
         rt = build_runtime()
         so = os.path.join(BUILD, "f_%s.so" % key)
@@ -355,7 +367,7 @@ class CpuFilter:
                 f.write(self.source)
             # the reference's CGEN_CC / CGEN_LD (Makefile:58-60)
             _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE, "-o", ofile, cfile])
-            _run(["gcc", "-shared", "-o", so + ".tmp", ofile, rt, "-lm"])
+            _run(["gcc", "-shared", "-o", so + ".tmp", ofile, rt] + noise + ["-lm"])
             os.replace(so + ".tmp", so)
         self.lib = C.CDLL(so)
         self.lib.mmo_xy_size.restype = C.c_int
