@@ -17,6 +17,10 @@ struct NativeWorkspace {
     size_t scratch_bytes = 0;
     void *reserve(size_t bytes);
     void release();
+    // cached hipFFT plans of the FFT native filters (native_fft.hip)
+    void *fft_fwd = nullptr, *fft_inv = nullptr;
+    int fft_w = 0, fft_h = 0, fft_batch = 0;
+    bool fft_valid = false;
 };
 
 // Runs native filter `func` with the arguments recorded by the prologue kernel.
@@ -24,6 +28,13 @@ struct NativeWorkspace {
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
                       std::string *err);
+
+// native_fft.hip: convolve / half_convolve / visualize_fft (native-filters/convolve.c)
+int fft_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images, int render_w,
+                      int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream, std::string *err);
+int native_input_map(const char *who, const HImage &img, const std::vector<HImageDesc> &images, int w, int h, float *dst,
+                     const float **map, hipStream_t s, std::string *err);
+void fft_release_plans(NativeWorkspace &ws);
 
 void launch_supersample_combine(const unsigned char *longs, const unsigned char *shorts, unsigned char *out, int w, int h,
                                 int bpp, int out_stride, hipStream_t s);

@@ -30,6 +30,7 @@ void *NativeWorkspace::reserve(size_t bytes) {
 }
 
 void NativeWorkspace::release() {
+    fft_release_plans(*this);
     if (scratch) (void)hipFree(scratch);
     scratch = nullptr;
     scratch_bytes = 0;
@@ -450,6 +451,22 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
 
 }  // namespace
 
+// The argument image of a native filter as a float map of w x h pixels: its own data when
+// it already is one of that size, otherwise render_image into `dst` (convolve.c:88-95).
+int native_input_map(const char *who, const HImage &img, const std::vector<HImageDesc> &images, int w, int h, float *dst,
+                     const float **map, hipStream_t s, std::string *err) {
+    if (img.idx < 0 || img.idx >= (int)images.size()) { *err = std::string(who) + ": input is not a bitmap image"; return -1; }
+    const HImageDesc &in = images[img.idx];
+    if (in.kind == IMG_FLOATMAP && in.w == w && in.h == h) { *map = (const float *)in.data; return 0; }
+    if (in.kind != IMG_DRAWABLE) { *err = std::string(who) + ": input image is not bound (or a float map of another size)"; return -1; }
+    const long n = (long)w * h;
+    k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        (const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y, in.middle_x, in.middle_y, img.resized, img.xf,
+        img.yf, 0u, 0u, 0, (float4 *)dst, w, h);
+    *map = dst;
+    return 0;
+}
+
 // Supersampling combine of call_invocation (mathmap_common.c:880-927): per output byte
 // (l1[c] + l1[c+1] + 2*l2[c] + l3[c] + l3[c+1]) / 6 in integer arithmetic, where l1/l3 are
 // rows r and r+1 of the "long" slice (width+1, offset -0.5) and l2 row r of the short slice.
@@ -500,7 +517,9 @@ int run_native_filter(const std::string &func, const HNativeRec &rec, const std:
             img.yf, 0u, 0u, 0, (float4 *)out_map, w, h);
         return 0;
     }
-    *err = "native filter " + func + " is not implemented in the HIP backend yet";
+    if (func == "native_filter_convolve" || func == "native_filter_half_convolve" || func == "native_filter_visualize_fft")
+        return fft_native_filter(func, rec, images, render_w, render_h, out_map, ws, stream, err);
+    *err = "native filter " + func + " is not implemented in the HIP backend";
     return -1;
 }
 

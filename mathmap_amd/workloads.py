@@ -332,6 +332,28 @@ filter main (image in)
 end
 """
 
+# examples/Utilities/Visualize FFT.mm, examples/Combine/Convolve.mm, Half Convolve.mm
+# (the native FFT filters, native-filters/convolve.c)
+VISUALIZE_FFT = """
+stretched filter util_visualize_fft (stretched image in, bool ignore_alpha (1))
+  visualize_fft(in, ignore_alpha, xy)
+end
+"""
+
+CONVOLVE = """
+filter combine_convolve (image in, image kernel, bool normalize (1), bool copy_alpha (1))
+  convolved = convolve(in, kernel, normalize, copy_alpha);
+  convolved(xy)
+end
+"""
+
+HALF_CONVOLVE = """
+filter combine_half_convolve (image in, image mask, bool copy_alpha (1))
+  convolved = half_convolve(in, mask, copy_alpha);
+  convolved(xy)
+end
+"""
+
 ALL = {
     "ident": IDENT,
     "mandelbrot": MANDELBROT,
@@ -343,6 +365,9 @@ ALL = {
     "closure_value": CLOSURE_VALUE,
     "closure_arg": CLOSURE_ARG,
     "nested_calls": NESTED_CALLS,
+    "visualize_fft": VISUALIZE_FFT,
+    "convolve": CONVOLVE,
+    "half_convolve": HALF_CONVOLVE,
 }
 
 

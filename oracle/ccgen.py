@@ -123,7 +123,10 @@ class Gen:
                 return "mmo_closure_image(A)"
             slot = self.natives[id(stmt)]
             args = ", ".join(self.prim(a) for a in r["args"])
-            fn = {"native_filter_gaussian_blur": "mmo_native_gaussian_blur"}.get(r["native"])
+            fn = {"native_filter_gaussian_blur": "mmo_native_gaussian_blur",
+                  "native_filter_convolve": "mmo_native_convolve",
+                  "native_filter_half_convolve": "mmo_native_half_convolve",
+                  "native_filter_visualize_fft": "mmo_native_visualize_fft"}.get(r["native"])
             if fn is None:
                 raise OracleUnsupported("native filter %s" % r["native"])
             return "%s(A, %d, %s)" % (fn, slot, args)
@@ -338,14 +341,19 @@ def _run(cmd):
 
 
 def build_runtime():
-    """Compiles oracle/mm_oracle_rt.c once (gcc -O2 -fPIC, like the reference's own objects)."""
+    """Compiles the oracle's C runtime once (gcc -O2 -fPIC, like the reference's own objects)
+    and returns the object files to link into every generated filter."""
     os.makedirs(BUILD, exist_ok=True)
-    obj = os.path.join(BUILD, "mm_oracle_rt.o")
-    src = os.path.join(HERE, "mm_oracle_rt.c")
     hdr = os.path.join(HERE, "mm_oracle.h")
-    if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-o", obj, src])
-    return obj
+    objs = []
+    for name in ("mm_oracle_rt", "mm_oracle_fft"):
+        obj = os.path.join(BUILD, name + ".o")
+        src = os.path.join(HERE, name + ".c")
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-o", obj + ".tmp", src])
+            os.replace(obj + ".tmp", obj)
+        objs.append(obj)
+    return objs
 
 
 class CpuFilter:
@@ -360,14 +368,14 @@ class CpuFilter:
         key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
         rt = build_runtime()
         so = os.path.join(BUILD, "f_%s.so" % key)
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(rt):
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in rt):
             cfile = os.path.join(BUILD, "f_%s.c" % key)
             ofile = os.path.join(BUILD, "f_%s.o" % key)
             with open(cfile, "w") as f:
                 f.write(self.source)
             # the reference's CGEN_CC / CGEN_LD (Makefile:58-60)
             _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE, "-o", ofile, cfile])
-            _run(["gcc", "-shared", "-o", so + ".tmp", ofile, rt] + noise + ["-lm"])
+            _run(["gcc", "-shared", "-o", so + ".tmp", ofile] + rt + noise + ["-lm"])
             os.replace(so + ".tmp", so)
         self.lib = C.CDLL(so)
         self.lib.mmo_xy_size.restype = C.c_int

@@ -13,6 +13,7 @@
  *   image scale values       userval.c:262-280, floatmap.c:30-46
  *   render_image             builtins/builtins.c:267-346
  *   gaussian_blur            native-filters/gauss.c:38-262,641-670
+ *   convolve/half_convolve/visualize_fft   native-filters/convolve.c (mm_oracle_fft.c)
  *
  * Pinning: tests/test_oracle_golden.py checks it against the reference's own golden
  * PNGs (tests/golden/*.png, copied from the reference's tests/ directory).
@@ -57,7 +58,7 @@ typedef union { int i; float f; color_t c; int image; } mmo_userval;
 typedef struct mmo_native_memo {
     int valid;
     int func;
-    int in_idx;
+    int in_idx, in2_idx;
     float a1, a2;
     float *map;
     int w, h;
@@ -170,6 +171,9 @@ void mmo_store_pixel(const mmo_args *A, unsigned char *p, float *fp, const float
 
 /* native filters; `slot` = index of the call site (result lands in images[native_slot_base+slot]) */
 mmo_image mmo_native_gaussian_blur(const mmo_args *A, int slot, mmo_image in, float hdev, float vdev);
+mmo_image mmo_native_convolve(const mmo_args *A, int slot, mmo_image in, mmo_image filter, float normalize, float copy_alpha);
+mmo_image mmo_native_half_convolve(const mmo_args *A, int slot, mmo_image in, mmo_image filter, float copy_alpha);
+mmo_image mmo_native_visualize_fft(const mmo_args *A, int slot, mmo_image in, float ignore_alpha);
 mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h);
 void mmo_render_image(const mmo_args *A, const mmo_image_desc *src, mmo_image srcv, int w, int h, float *out);
 void mmo_gauss_iir(float *map, int width, int height, float hdev, float vdev);

@@ -35,6 +35,8 @@ GOLDEN = [
     ("closure_call", "circle.png", {}, True, 0),
     ("closure_arg", "closure.png", {}, True, 0),
     ("nested_calls", "twice.png", {}, True, 0),
+    # native FFT filter: the oracle's direct DFT against the reference's FFTW-made golden
+    ("visualize_fft", "utilities_visualize_fft.png", {}, True, 0),
 ]
 
 
@@ -274,6 +276,63 @@ def test_float_add_half_and_floor_identities():
     assert np.array_equal((1.0 - f.astype(np.float64)).astype(np.float32), np.float32(1.0) - f)
 
 
+def test_oracle_dft_against_numpy_fft():
+    """The oracle's direct long-double DFT (oracle/mm_oracle_fft.c) against numpy's pocketfft
+    for the two transforms the reference asks of FFTW (r2c_2d, c2r_2d), even and odd sizes.
+    Tolerance: 1e-12 of the largest output magnitude (double FFT round-off is ~1e-15)."""
+    import ctypes as C
+    import subprocess
+    from oracle import ccgen
+    rt = ccgen.build_runtime()
+    so = os.path.join(ccgen.BUILD, "rt_only.so")
+    subprocess.run(["gcc", "-shared", "-o", so] + rt + ["-lm"], check=True)
+    lib = C.CDLL(so)
+    rng = np.random.default_rng(5)
+    for w, h in [(16, 8), (15, 9), (32, 31), (1, 7), (6, 1)]:
+        x = rng.uniform(-1, 1, (h, w))
+        cw = w // 2 + 1
+        out = np.zeros((h, cw), np.complex128)
+        lib.mmo_dft_r2c_2d(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w, h)
+        want = np.fft.rfft2(x)
+        assert np.abs(out - want).max() <= 1e-12 * np.abs(want).max(), (w, h)
+        back = np.zeros((h, w))
+        lib.mmo_dft_c2r_2d(want.copy().ctypes.data_as(C.c_void_p), back.ctypes.data_as(C.c_void_p), w, h)
+        assert np.abs(back / (w * h) - x).max() <= 1e-12, (w, h)
+        # a spectrum that is not Hermitian in its kx = 0 column (what half_convolve produces):
+        # column inverse first, then the real row inverse -- numpy's irfft2 does the same
+        spec = want * rng.uniform(0, 1, want.shape)
+        lib.mmo_dft_c2r_2d(spec.copy().ctypes.data_as(C.c_void_p), back.ctypes.data_as(C.c_void_p), w, h)
+        ref = np.fft.irfft(np.fft.ifft(spec, axis=0), n=w, axis=1) * (w * h)
+        assert np.abs(back - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (w, h)
+
+
+def test_oracle_convolve_identities(marlene):
+    """convolve with a centred unit impulse is the identity; with normalize the kernel's
+    scale drops out; half_convolve with an all-ones mask is the identity (<= 1 LSB: the
+    result goes double -> float -> byte)."""
+    h, w = 48, 64
+    img = np.ascontiguousarray(marlene[:h, :w])
+    kern = np.zeros((h, w, 3), np.uint8)
+    kern[h // 2 - 1, w // 2] = 255      # index n - nhalf of the flat map lands on [0][0] (convolve.c:119-122)
+    src = "filter c (image in, image kernel, bool norm (1)) cv = convolve(in, kernel, norm, 1); cv(xy) end"
+    flt = mm.Filter(src)
+    cpu = CpuFilter(flt.ir_json)
+    ident = CpuFilter(mm.Filter("filter i (image in) in(xy) end").ir_json).render(w, h, images={"in": img})
+    for norm in (1, 0):
+        got = cpu.render(w, h, uservals={"norm": norm}, images={"in": img, "kernel": kern})
+        assert np.abs(got.astype(int) - ident.astype(int)).max() <= 1, norm
+    grey = np.full((h, w, 3), 93, np.uint8)
+    dim = (kern // 3).astype(np.uint8)
+    a = cpu.render(w, h, uservals={"norm": 1}, images={"in": img, "kernel": kern})
+    b = cpu.render(w, h, uservals={"norm": 1}, images={"in": img, "kernel": dim})
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    ones = np.full((h, w, 3), 255, np.uint8)
+    hc = CpuFilter(mm.Filter("filter hc (image in, image mask) c = half_convolve(in, mask, 1); c(xy) end").ir_json)
+    got = hc.render(w, h, images={"in": img, "mask": ones})
+    assert np.abs(got.astype(int) - ident.astype(int)).max() <= 1
+    del grey
+
+
 def test_oracle_cgamma_matches_reference_build():
     """oracle cgamma vs the reference's own builtins/spec_func.c compiled into oracle/_ref
     (bit-identical), and the known answer of its TEST_CGAMMA main: cgamma(2.5+0.5i)."""
@@ -282,7 +341,7 @@ def test_oracle_cgamma_matches_reference_build():
     ref = os.path.join(ROOT, "oracle", "_ref", "libspec_func.so")
     rt = ccgen.build_runtime()
     so = os.path.join(ccgen.BUILD, "rt_only.so")
-    subprocess.run(["gcc", "-shared", "-o", so, rt, "-lm"], check=True)
+    subprocess.run(["gcc", "-shared", "-o", so] + rt + ["-lm"], check=True)
     prog = r'''
 #include <complex.h>
 #include <stdio.h>

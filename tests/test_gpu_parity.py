@@ -46,6 +46,7 @@ GOLDEN_CASES = [
     ("closure_call", "circle.png", {}, True, 0),
     ("closure_arg", "closure.png", {}, True, 0),
     ("nested_calls", "twice.png", {}, True, 0),
+    ("visualize_fft", "utilities_visualize_fft.png", {}, True, 1),
 ]
 
 
@@ -343,6 +344,68 @@ def test_specialised_mandelbrot_8192_equals_generic():
     a = mm.Filter(W.MANDELBROT).invoke(w, h).render()
     b = mm.Filter(W.MANDELBROT, specialize=True).invoke(w, h).render()
     assert np.array_equal(a, b)
+
+
+def _fft_case(src, w, h, uv, images):
+    flt = mm.Filter(src)
+    inv = flt.invoke(w, h)
+    for k, v in uv.items():
+        inv.set(k, v)
+    for k, v in images.items():
+        inv.set_image(k, v)
+    got = inv.render()
+    want = CpuFilter(flt.ir_json).render(w, h, uservals=uv, images=images)
+    return got, want
+
+
+@pytest.mark.parametrize("w,h", [(96, 64), (75, 50), (64, 33)])
+def test_fft_native_filters_match_oracle(w, h):
+    """convolve / half_convolve / visualize_fft (hipFFT double + hand-written kernels) against
+    the oracle's direct long-double DFT, even and odd sizes, every flag combination.
+    Tolerance: the reference itself uses FFTW, whose round-off differs from any other FFT's
+    by O(1e-15) relative; after /n, the float store and the byte pack that is <= 1 LSB."""
+    img = W.synthetic_image(w, h, seed=3)
+    yy, xx = np.mgrid[0:h, 0:w]
+    blob = np.exp(-(((xx - w // 2) / 3.0) ** 2 + ((yy - (h // 2 - 1)) / 2.0) ** 2))
+    kern = np.repeat((blob * 255).astype(np.uint8)[:, :, None], 3, axis=2)
+    kern[:, :, 1] = kern[:, :, 1] // 2
+    mask = W.synthetic_image(w, h, seed=9)
+    for normalize in (0, 1):
+        for copy_alpha in (0, 1):
+            got, want = _fft_case(W.CONVOLVE, w, h, {"normalize": normalize, "copy_alpha": copy_alpha},
+                                  {"in": img, "kernel": kern})
+            mx, nd, n1 = stats(got, want)
+            assert mx <= 1, ("convolve", w, h, normalize, copy_alpha, mx, nd, n1)
+    for copy_alpha in (0, 1):
+        got, want = _fft_case(W.HALF_CONVOLVE, w, h, {"copy_alpha": copy_alpha}, {"in": img, "mask": mask})
+        mx, nd, n1 = stats(got, want)
+        assert mx <= 1, ("half_convolve", w, h, copy_alpha, mx, nd, n1)
+    for ignore_alpha in (0, 1):
+        got, want = _fft_case(W.VISUALIZE_FFT, w, h, {"ignore_alpha": ignore_alpha}, {"in": img})
+        mx, nd, n1 = stats(got, want)
+        assert mx <= 1, ("visualize_fft", w, h, ignore_alpha, mx, nd, n1)
+
+
+def test_convolve_with_impulse_is_identity_at_2048():
+    """Size-independent property at a size the oracle cannot reach: convolving with the unit
+    impulse at flat index n - nhalf (convolve.c:119-122) returns the input (<= 1 LSB), and
+    the native-filter memo returns the same map on a second frame."""
+    w = h = 2048
+    img = W.synthetic_image(w, h, seed=5)
+    kern = np.zeros((h, w, 3), np.uint8)
+    kern[h // 2 - 1, w // 2] = 255
+    flt = mm.Filter(W.CONVOLVE)
+    inv = flt.invoke(w, h)
+    inv.set("normalize", 1)
+    inv.set_image("in", img)
+    inv.set_image("kernel", kern)
+    got = inv.render()
+    ident = mm.Filter(W.IDENT).invoke(w, h)
+    ident.set_image("in", img)
+    want = ident.render()
+    mx, nd, n1 = stats(got, want)
+    assert mx <= 1, (mx, nd, n1)
+    assert np.array_equal(inv.render(t=0.5), got)
 
 
 def _ir_manifest():
