@@ -30,6 +30,9 @@ class Filter:
 
     def __init__(self, source, intersample=True, supersampling=False, edge_x=EDGE_COLOR, edge_y=EDGE_COLOR,
                  tile_w=0, specialize=False, constants=None, ir_json=None):
+        self._source = source
+        self._kwargs = dict(intersample=intersample, supersampling=supersampling, edge_x=edge_x, edge_y=edge_y,
+                            tile_w=tile_w)
         o = Options()
         lib().mmhip_default_options(C.byref(o))
         o.intersample = 1 if intersample else 0
@@ -86,6 +89,29 @@ class Filter:
     @property
     def ir_json(self):
         return lib().mmhip_filter_ir_json(self._h).decode()
+
+    @property
+    def needs_constants(self):
+        """True for a filter that only compiles once its scalar user values are literals
+        (recursion whose depth they control): it has no generic IR/kernel, every render
+        builds -- and caches -- the variant for the current values."""
+        return self.ir_json == ""
+
+    def specialized(self, values=None):
+        """The variant with every int/float/bool user value baked in: the declared defaults,
+        overridden by `values` (name -> number).  What a render with those values runs."""
+        consts = {}
+        for u in self.uservals:
+            if u["kind"] == UV_INT:
+                consts[u["name"]] = u["int_default"]
+            elif u["kind"] == UV_FLOAT:
+                consts[u["name"]] = u["float_default"]
+            elif u["kind"] == UV_BOOL:
+                consts[u["name"]] = u["bool_default"]
+        for k, v in (values or {}).items():
+            if k in consts:
+                consts[k] = v
+        return Filter(self._source, constants=consts, **self._kwargs)
 
     @property
     def kernel_source(self):

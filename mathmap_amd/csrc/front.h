@@ -20,6 +20,9 @@ namespace mm {
 
 struct CompileError : std::runtime_error {
     int pos;
+    // the failure goes away once the main filter's scalar user values are literals
+    // (recursion whose depth they control): the runtime then compiles per value set
+    bool needs_constants = false;
     CompileError(const std::string &m, int p = -1) : std::runtime_error(m), pos(p) {}
 };
 

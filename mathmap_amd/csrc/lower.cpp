@@ -13,6 +13,7 @@
 
 #include "front.h"
 #include "gen.h"
+#include "passes.h"
 
 namespace mm {
 
@@ -45,6 +46,8 @@ class Lowerer {
     Gen g_;
     Env *env_ = nullptr;
     std::vector<Filter *> inlining_;
+    int while_depth_ = 0;
+    enum { MAX_RECURSION = 64 };   // activations of one filter on the inlining stack
 
     bool needs_xy_scaling(unsigned flags) const {
         return (flags & (IMAGE_FLAG_UNIT | IMAGE_FLAG_SQUARE)) != IMAGE_FLAG_UNIT;
@@ -67,6 +70,7 @@ class Lowerer {
     void gen_func(AstNode *n, CompVar **dest, bool alloced);
     void gen_closure(AstNode *n, CompVar **dest, bool alloced);
     bool single_const(AstNode *n, int *iv);
+    bool const_value(const Value *v, Primary *out, int depth = 0);
     ImageChain resolve_image(Value *v);
     void alloc_var(Variable *v);
     void reset_vars(FilterVars *fv);
@@ -177,8 +181,18 @@ void Lowerer::alloc_var(Variable *v) {
 // compiler.c:2610-2664.  `args` = closure arguments followed by x, y, t for an
 // inlined call; nullptr for the main filter.
 void Lowerer::gen_filter(Filter *f, const std::vector<Primary> *args, CompVar *result[4]) {
-    for (Filter *h : inlining_)
-        if (h == f) throw CompileError("recursive filter `" + f->name + "' is not supported by the HIP backend yet");
+    // Filter calls are inlined, so recursion must bottom out while lowering: an `if' whose
+    // condition folds to a literal (const_value) only lowers the taken branch.  The reference
+    // calls filter_<name> recursively at run time (compiler.c:2165-2222, backends/cc.c:189);
+    // here the recursion depth has to be fixed by literals or baked-in user values.
+    int active = 0;
+    for (Filter *h : inlining_) active += h == f;
+    if (active >= MAX_RECURSION) {
+        CompileError e("recursive filter `" + f->name + "': the recursion does not end for compile-time-constant "
+                       "arguments (the HIP backend unrolls recursion, its depth must be fixed by the user values)");
+        e.needs_constants = uv_consts_ == nullptr;
+        throw e;
+    }
     inlining_.push_back(f);
     Env env;
     env.filter = f;
@@ -263,6 +277,27 @@ bool Lowerer::single_const(AstNode *n, int *iv) {
             return false;
         default: return false;
     }
+}
+
+// The literal an SSA value is known to hold while lowering (copies and foldable ops of
+// literals), used to decide `if's at compile time.  Only asked outside loops: inside one, a
+// value defined before the loop may still be rewritten into a loop phi (gen.cpp commit()).
+bool Lowerer::const_value(const Value *v, Primary *out, int depth) {
+    if (!v || v->index < 0 || depth > 64) return false;
+    const Stmt *d = v->def;
+    if (!d || d->kind != Stmt::Assign) return false;
+    const Rhs &r = d->rhs;
+    auto prim = [&](const Primary &p, Primary *o) {
+        if (p.kind == Primary::IntConst || p.kind == Primary::FloatConst) { *o = p; return true; }
+        if (p.kind == Primary::Val) return const_value(p.value, o, depth + 1);
+        return false;
+    };
+    if (r.kind == Rhs::Prim) return prim(r.prim, out);
+    if (r.kind != Rhs::Op) return false;
+    std::vector<Primary> cs(r.args.size());
+    for (size_t i = 0; i < r.args.size(); ++i)
+        if (!prim(r.args[i], &cs[i])) return false;
+    return fold_constant_op(r.op, cs, *out);
 }
 
 // Follows an image value's definitions through copies, STRIP_RESIZE and
@@ -446,11 +481,20 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
             std::vector<CompVar *> result(n->result.len);
             for (auto &r : result) r = g_.temp(is_image ? Ty::Image : Ty::Int);
             std::vector<CompVar *> cond = gen_new(n->kids[0]);
-            g_.start_if(Rhs::V(cond[0]->current));
-            gen(n->kids[1], result.data(), true);
-            g_.switch_branch();
-            if (n->kind == AstNode::IfThenElse) gen(n->kids[2], result.data(), true);
-            g_.end_if();
+            Primary known;
+            if (while_depth_ == 0 && const_value(cond[0]->current, &known)) {
+                // decided at compile time: lower the taken branch only (this is what lets a
+                // recursive filter whose depth is a literal / baked-in user value terminate)
+                const bool truth = known.kind == Primary::IntConst ? known.i != 0 : known.f != 0.0f;
+                if (truth) gen(n->kids[1], result.data(), true);
+                else if (n->kind == AstNode::IfThenElse) gen(n->kids[2], result.data(), true);
+            } else {
+                g_.start_if(Rhs::V(cond[0]->current));
+                gen(n->kids[1], result.data(), true);
+                g_.switch_branch();
+                if (n->kind == AstNode::IfThenElse) gen(n->kids[2], result.data(), true);
+                g_.end_if();
+            }
             for (int i = 0; i < n->result.len; ++i) {
                 if (alloced) g_.copy(dest[i], result[i]);
                 else dest[i] = result[i];
@@ -463,8 +507,10 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
             if (n->kind == AstNode::DoWhile) gen_new(n->kids[1]);
             gen(n->kids[0], &inv, true);
             g_.start_while(inv);
+            ++while_depth_;
             gen_new(n->kids[1]);
             gen(n->kids[0], &inv, true);
+            --while_depth_;
             g_.end_while();
             if (!alloced) dest[0] = g_.temp();
             g_.assign(dest[0], Rhs::I(0));

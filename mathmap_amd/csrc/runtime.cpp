@@ -70,7 +70,20 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
     std::unique_ptr<mmhip_filter> f(new mmhip_filter());
     try {
         parse_module(f->module, source);
-        f->code = lower_filter(f->module, f->module.main, consts);
+        f->source = source;
+        if (opts) f->opts = *opts;
+        try {
+            f->code = lower_filter(f->module, f->module.main, consts);
+        } catch (const CompileError &e) {
+            if (!e.needs_constants) throw;
+            // recursion controlled by user values: no generic kernel exists, every value set
+            // gets its own (active_filter); the filter is usable for invoke/set/render
+            f->deferred = true;
+            f->deferred_reason = e.what();
+            f->specialize = true;
+            f->opts.specialize_uservals = 1;
+            return f.release();
+        }
         if (consts) specialize_constants(*f->code);
         optimize(*f->code);
         analyze_frame_constants(*f->code);
@@ -176,6 +189,7 @@ int mmhip_filter_num_native_calls(const mmhip_filter *f) { return (int)f->ks.nat
 double mmhip_filter_jit_seconds(const mmhip_filter *f) { return f->jit_seconds; }
 
 long mmhip_filter_jit(mmhip_filter *f, int load_module) {
+    if (f->deferred) return 0;     // kernels are built per user-value set at render time
     auto t0 = std::chrono::steady_clock::now();
     if (f->code_object.empty()) {
         std::string path = cache_dir() + "/" + f->ks.key + ".hsaco";
@@ -288,11 +302,12 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
     if ((e = hipStreamCreate(&inv->stream)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc((void **)&inv->d_uv, inv->uv.size() * sizeof(HUserval))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&inv->d_images, inv->images.size() * sizeof(HImageDesc))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void **)&inv->d_xy, f->ks.xy_bytes)) != hipSuccess) return bail("hipMalloc", e);
+    const int xy_bytes = std::max(f->ks.xy_bytes, 256);
+    if ((e = hipMalloc((void **)&inv->d_xy, xy_bytes)) != hipSuccess) return bail("hipMalloc", e);
     if (!inv->curves.empty() && (e = hipMalloc((void **)&inv->d_curves, inv->curves.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
     if (!inv->gradients.empty() && (e = hipMalloc((void **)&inv->d_gradients, inv->gradients.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(inv->d_xy, 0, f->ks.xy_bytes)) != hipSuccess) return bail("hipMemset", e);
-    inv->xy_cap = f->ks.xy_bytes;
+    if ((e = hipMemset(inv->d_xy, 0, xy_bytes)) != hipSuccess) return bail("hipMemset", e);
+    inv->xy_cap = xy_bytes;
     return inv.release();
 }
 
@@ -517,6 +532,7 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
 static mmhip_filter *active_filter(mmhip_invocation *inv) {
     mmhip_filter *f = inv->f;
     if (!f->specialize || !f->ks.natives.empty() || f->source.empty()) return f;
+    g_err.clear();
     const auto &uvs = f->module.main->uservals;
     std::string key;
     std::map<int, Primary> consts;
@@ -540,6 +556,7 @@ static mmhip_filter *active_filter(mmhip_invocation *inv) {
 int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
                  int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream) {
     mmhip_filter *f = active_filter(inv);
+    if (f->deferred) return fail(g_err.empty() ? f->deferred_reason : g_err);
     hipStream_t s = stream ? (hipStream_t)stream : inv->stream;
     if (bpp < 1 || bpp > 4) return fail("output_bpp must be 1..4");
     if (region_w <= 0 || region_h <= 0) return fail("empty region");

@@ -30,6 +30,10 @@ struct mmhip_filter {
     mmhip_options opts{};
     bool specialize = false;
     std::map<std::string, mmhip_filter *> spec_cache;
+    // a filter that only compiles with its scalar user values baked in (recursion whose depth
+    // they control): no generic code/kernels, every render goes through spec_cache
+    bool deferred = false;
+    std::string deferred_reason;
 };
 
 struct mmhip_invocation {

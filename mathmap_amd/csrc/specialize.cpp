@@ -59,7 +59,42 @@ bool convert_to(Ty t, Primary &p) {
     return false;
 }
 
+bool both_int(const Primary &a, const Primary &b) { return a.kind == Primary::IntConst && b.kind == Primary::IntConst; }
+
+// folds an operator on constants with the C semantics of its macro (opmacros.h)
+bool fold_impl(const OpInfo *op, const std::vector<Primary> &a, Primary &out) {
+    const char *n = op->cname;
+    auto bin = [&](auto fi, auto fd) {
+        if (both_int(a[0], a[1])) out = Primary::I(fi(a[0].i, a[1].i));
+        else out = Primary::F((float)fd(as_double(a[0]), as_double(a[1])));   // double op, one rounding (innocuous for + - *)
+        return true;
+    };
+    if (!strcmp(n, "ADD")) return bin([](int x, int y) { return (int)((unsigned)x + (unsigned)y); }, [](double x, double y) { return x + y; });
+    if (!strcmp(n, "SUB")) return bin([](int x, int y) { return (int)((unsigned)x - (unsigned)y); }, [](double x, double y) { return x - y; });
+    if (!strcmp(n, "MUL")) return bin([](int x, int y) { return (int)((unsigned)x * (unsigned)y); }, [](double x, double y) { return x * y; });
+    if (!strcmp(n, "NEG")) {
+        out = a[0].kind == Primary::IntConst ? Primary::I((int)(0u - (unsigned)a[0].i)) : Primary::F(-a[0].f);
+        return true;
+    }
+    if (!strcmp(n, "DIV")) { out = Primary::F((float)as_double(a[0]) / (float)as_double(a[1])); return true; }
+    auto cmp = [&](auto f) { out = Primary::I(both_int(a[0], a[1]) ? f((double)a[0].i, (double)a[1].i) : f(as_double(a[0]), as_double(a[1]))); return true; };
+    if (!strcmp(n, "EQ")) return cmp([](double x, double y) { return x == y ? 1 : 0; });
+    if (!strcmp(n, "LESS")) return cmp([](double x, double y) { return x < y ? 1 : 0; });
+    if (!strcmp(n, "LEQ")) return cmp([](double x, double y) { return x <= y ? 1 : 0; });
+    if (!strcmp(n, "NOT") && a[0].kind == Primary::IntConst) { out = Primary::I(!a[0].i); return true; }
+    if (!strcmp(n, "MIN") || !strcmp(n, "MAX")) {
+        bool pick_first = !strcmp(n, "MIN") ? as_double(a[0]) < as_double(a[1]) : !(as_double(a[0]) < as_double(a[1]));
+        const Primary &p = pick_first ? a[0] : a[1];
+        out = both_int(a[0], a[1]) ? p : Primary::F((float)as_double(p));
+        return true;
+    }
+    if (!strcmp(n, "INT2FLOAT") && a[0].kind == Primary::IntConst) { out = Primary::F((float)a[0].i); return true; }
+    return false;   // libm and everything else stays in the kernel / prologue
+}
+
 struct Sccp {
+    static bool fold(const OpInfo *op, const std::vector<Primary> &a, Primary &out) { return fold_impl(op, a, out); }
+
     FilterCode &code;
     std::map<const Value *, Lat> lat;
     bool changed = false;
@@ -79,39 +114,6 @@ struct Sccp {
         }
         auto it = lat.find(v);
         return it == lat.end() ? Lat() : it->second;
-    }
-
-    static bool both_int(const Primary &a, const Primary &b) { return a.kind == Primary::IntConst && b.kind == Primary::IntConst; }
-
-    // folds an operator on constants with the C semantics of its macro (opmacros.h)
-    bool fold(const OpInfo *op, const std::vector<Primary> &a, Primary &out) {
-        const char *n = op->cname;
-        auto bin = [&](auto fi, auto fd) {
-            if (both_int(a[0], a[1])) out = Primary::I(fi(a[0].i, a[1].i));
-            else out = Primary::F((float)fd(as_double(a[0]), as_double(a[1])));   // double op, one rounding (innocuous for + - *)
-            return true;
-        };
-        if (!strcmp(n, "ADD")) return bin([](int x, int y) { return (int)((unsigned)x + (unsigned)y); }, [](double x, double y) { return x + y; });
-        if (!strcmp(n, "SUB")) return bin([](int x, int y) { return (int)((unsigned)x - (unsigned)y); }, [](double x, double y) { return x - y; });
-        if (!strcmp(n, "MUL")) return bin([](int x, int y) { return (int)((unsigned)x * (unsigned)y); }, [](double x, double y) { return x * y; });
-        if (!strcmp(n, "NEG")) {
-            out = a[0].kind == Primary::IntConst ? Primary::I((int)(0u - (unsigned)a[0].i)) : Primary::F(-a[0].f);
-            return true;
-        }
-        if (!strcmp(n, "DIV")) { out = Primary::F((float)as_double(a[0]) / (float)as_double(a[1])); return true; }
-        auto cmp = [&](auto f) { out = Primary::I(both_int(a[0], a[1]) ? f((double)a[0].i, (double)a[1].i) : f(as_double(a[0]), as_double(a[1]))); return true; };
-        if (!strcmp(n, "EQ")) return cmp([](double x, double y) { return x == y ? 1 : 0; });
-        if (!strcmp(n, "LESS")) return cmp([](double x, double y) { return x < y ? 1 : 0; });
-        if (!strcmp(n, "LEQ")) return cmp([](double x, double y) { return x <= y ? 1 : 0; });
-        if (!strcmp(n, "NOT") && a[0].kind == Primary::IntConst) { out = Primary::I(!a[0].i); return true; }
-        if (!strcmp(n, "MIN") || !strcmp(n, "MAX")) {
-            bool pick_first = !strcmp(n, "MIN") ? as_double(a[0]) < as_double(a[1]) : !(as_double(a[0]) < as_double(a[1]));
-            const Primary &p = pick_first ? a[0] : a[1];
-            out = both_int(a[0], a[1]) ? p : Primary::F((float)as_double(p));
-            return true;
-        }
-        if (!strcmp(n, "INT2FLOAT") && a[0].kind == Primary::IntConst) { out = Primary::F((float)a[0].i); return true; }
-        return false;   // libm and everything else stays in the kernel / prologue
     }
 
     Lat eval(const Rhs &r, const CompVar *lhs) {
@@ -322,5 +324,7 @@ void specialize_constants(FilterCode &code) {
         if (!c && round > 0) break;
     }
 }
+
+bool fold_constant_op(const OpInfo *op, const std::vector<Primary> &args, Primary &out) { return fold_impl(op, args, out); }
 
 }  // namespace mm

@@ -354,6 +354,22 @@ filter combine_half_convolve (image in, image mask, bool copy_alpha (1))
 end
 """
 
+# A recursive filter (the shape of examples/Map/IFS Functional.mm: the recursion depth is a
+# user value).  Filter calls are inlined, so the HIP backend unrolls it per depth value.
+RECURSIVE = """
+filter shrink (image in, float s)
+  in(xy / s)
+end
+
+filter tree (image in, int depth: 1-16 (4), float s: 0-1 (0.6))
+  if depth < 2 then
+    in(xy)
+  else
+    in(xy) * 0.5 + shrink(tree(in, depth - 1, s), s, xy) * 0.5
+  end
+end
+"""
+
 ALL = {
     "ident": IDENT,
     "mandelbrot": MANDELBROT,

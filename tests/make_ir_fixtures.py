@@ -30,12 +30,15 @@ def main():
         stem = os.path.splitext(golden)[0]
         try:
             flt = mm.Filter(open(os.path.join(REF, script)).read())
+            if flt.needs_constants:      # recursive filter: the variant for this case's user values
+                flt = flt.specialized(uv)
             flt.jit(load=False)      # must at least compile for gfx950
         except mm.MathMapError as e:
             print("skip %-40s %s" % (stem, str(e).splitlines()[0][:70]))
             continue
-        with gzip.open(os.path.join(OUT, stem + ".json.gz"), "wt", compresslevel=9) as f:
-            f.write(flt.ir_json)
+        with open(os.path.join(OUT, stem + ".json.gz"), "wb") as raw:      # mtime=0: reproducible bytes
+            with gzip.GzipFile(fileobj=raw, mode="wb", compresslevel=9, mtime=0, filename="") as f:
+                f.write(flt.ir_json.encode())
         manifest.append({"ir": stem + ".json.gz", "golden": golden, "uservals": uv, "needs_image": needs})
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
     print("%d fixtures" % len(manifest))

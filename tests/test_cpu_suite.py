@@ -18,6 +18,8 @@ from tests.conftest import REFERENCE, ROOT, load_png_rgb
 
 def oracle_render(src, uv=None, image=None, w=256, h=256, t=0.0, intersample=True):
     flt = mm.Filter(src)
+    if flt.needs_constants:      # recursion unrolled per user-value set (lower.cpp gen_filter)
+        flt = flt.specialized(uv)
     images = {"in": image} if image is not None else {}
     return CpuFilter(flt.ir_json).render(w, h, uservals=uv, images=images, t=t, intersample=intersample)
 
@@ -120,6 +122,23 @@ def test_oracle_sweep_over_reference_suite(marlene):
     json.dump({"matching": sorted(ok), "mismatching": bad, "unsupported": unsupported}, open(report, "w"), indent=1)
     assert not bad, bad
     assert len(ok) >= 55, (len(ok), unsupported)
+
+
+def test_recursive_filter_unrolls_per_user_value_set():
+    """A recursive filter has no generic kernel (needs_constants); with the depth baked in the
+    recursion is unrolled while lowering.  depth = 1 must equal the plain fetch, and an
+    unbounded recursion is a compile error, not a hang."""
+    flt = mm.Filter(W.RECURSIVE)
+    assert flt.needs_constants and [u["name"] for u in flt.uservals] == ["in", "depth", "s"]
+    img = W.synthetic_image(64, 48, seed=2)
+    one = CpuFilter(flt.specialized({"depth": 1}).ir_json).render(64, 48, images={"in": img})
+    ident = CpuFilter(mm.Filter(W.IDENT).ir_json).render(64, 48, images={"in": img})
+    assert np.array_equal(one, ident)
+    sizes = [len(flt.specialized({"depth": d}).ir_json) for d in (1, 2, 4)]
+    assert sizes[0] < sizes[1] < sizes[2]
+    with pytest.raises(mm.MathMapError) as e:
+        mm.Filter("filter f (image in, int d: 1-9 (3)) f(in, d, xy) end", constants={"d": 3})
+    assert "recursi" in str(e.value)
 
 
 # ---- host logic ----------------------------------------------------------------------------

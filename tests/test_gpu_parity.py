@@ -408,6 +408,26 @@ def test_convolve_with_impulse_is_identity_at_2048():
     assert np.array_equal(inv.render(t=0.5), got)
 
 
+def test_recursive_filter_renders_per_depth():
+    """Deferred (needs_constants) filter through the normal invoke/set/render path: each depth
+    value builds its own kernel; compared with the oracle on the same unrolled IR."""
+    w, h = 96, 64
+    img = W.synthetic_image(w, h, seed=2)
+    flt = mm.Filter(W.RECURSIVE)
+    assert flt.needs_constants
+    inv = flt.invoke(w, h)
+    inv.set_image("in", img)
+    outs = []
+    for depth in (1, 3, 5):
+        inv.set("depth", depth)
+        got = inv.render()
+        want = CpuFilter(flt.specialized({"depth": depth}).ir_json).render(w, h, images={"in": img})
+        mx, nd, n1 = stats(got, want)
+        assert mx <= 1, (depth, mx, nd, n1)
+        outs.append(got)
+    assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[1], outs[2])
+
+
 def _ir_manifest():
     import json
     import os
