@@ -179,6 +179,13 @@ struct Generator {
                         d->rhs.args[0].kind == Primary::Val && value_visible(d->rhs.args[0].value, sl))
                         return "MM_SQRT_LESS_POW2(" + prim(d->rhs.args[0], sl) + ", " + float_literal((float)(k * k)) + "f)";
                 }
+                if (sl == PIXEL && hot_mode && hot_sites.count(stmt))
+                    return "mm_orig_val_hot(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " + prim(r.args[2], sl) +
+                           ", " + vname(r.args[2].value) + "_desc)";
+                if (sl == PIXEL && !strcmp(cn, "ORIG_VAL") && r.args.size() == 4 && r.args[2].kind == Primary::Val &&
+                    preloaded_desc.count(r.args[2].value))
+                    return "mm_orig_val_d(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " + prim(r.args[2], sl) +
+                           ", " + prim(r.args[3], sl) + ", " + vname(r.args[2].value) + "_desc)";
                 std::string name = cn;
                 if (const char *lm = libm_name(cn)) name = lm;
                 // exact f32 fast path: (float)sqrt((double)f) == sqrtf(f), correctly rounded
@@ -229,6 +236,53 @@ struct Generator {
             if (s->kind == Stmt::While && uses_noise(s->body)) return true;
         }
         return false;
+    }
+
+    std::set<const Value *> preloaded_desc;   // image values whose descriptor is loaded before the pixel loop
+    std::set<const Stmt *> hot_sites;         // ORIG_VAL statements eligible for mm_orig_val_hot
+    bool hot_mode = false;
+
+    // ORIG_VALs of the pixel slice whose image descriptor is preloaded and whose frame
+    // argument is a literal or a frame constant: their "bound drawable, valid frame" test can
+    // be made once per work-item.  Appends one condition per site.
+    void find_hot_fetches(const Block &b, std::vector<std::string> &conds) {
+        for (const Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            if (s->kind == Stmt::Assign && s->rhs.kind == Rhs::Op && !strcmp(s->rhs.op->cname, "ORIG_VAL") &&
+                s->rhs.args.size() == 4 && s->rhs.args[2].kind == Primary::Val && preloaded_desc.count(s->rhs.args[2].value)) {
+                const Primary &f = s->rhs.args[3];
+                const bool frame_const = f.is_const() || (f.kind == Primary::Val && transfer_off.count(f.value));
+                if (frame_const) {
+                    hot_sites.insert(s);
+                    conds.push_back("mm_fetch_is_hot(" + vname(s->rhs.args[2].value) + "_desc, (int)(" + prim(f, PIXEL) + "))");
+                }
+            }
+            if (s->kind == Stmt::If) { find_hot_fetches(s->then_, conds); find_hot_fetches(s->else_, conds); }
+            if (s->kind == Stmt::While) find_hot_fetches(s->body, conds);
+        }
+    }
+
+    // pixel-slice statistics for the unroll choice
+    static void pixel_stats(const Block &b, int &stmts, int &fetches) {
+        for (const Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            ++stmts;
+            if (s->kind == Stmt::Assign && s->rhs.kind == Rhs::Op && !strcmp(s->rhs.op->cname, "ORIG_VAL")) ++fetches;
+            if (s->kind == Stmt::If) { pixel_stats(s->then_, stmts, fetches); pixel_stats(s->else_, stmts, fetches); }
+            if (s->kind == Stmt::While) pixel_stats(s->body, stmts, fetches);
+        }
+    }
+
+    // Filters that fetch pixels are bound by memory latency with one pixel in flight per
+    // work-item (measured: a nearest fetch cost 0.25 ms at 8192^2 against 0.06 ms for the
+    // store); evaluating two pixels back to back doubles the loads in flight.  Large bodies
+    // are left alone: twice the code and registers costs more occupancy than it gains.
+    int auto_unroll() const {
+        if (const char *e = getenv("MMHIP_UNROLL")) { int u = atoi(e); if (u >= 1 && u <= 8) return u; }
+        int stmts = 0, fetches = 0;
+        pixel_stats(code.body, stmts, fetches);
+        if (fetches == 0) return 1;
+        return stmts <= 400 ? 2 : 1;
     }
 
     void find_natives(Block &b) {
@@ -373,6 +427,8 @@ struct Generator {
         out << "#define MM_SUPERSAMPLING " << opt.supersampling << "\n";
         out << "#define MM_EDGE_X " << opt.edge_x << "\n#define MM_EDGE_Y " << opt.edge_y << "\n";
         out << "#define MM_TILE_W " << ks.tile_w << "\n#define MM_TILE_H " << ks.tile_h << "\n";
+        ks.unroll = opt.unroll > 0 ? opt.unroll : auto_unroll();
+        out << "#define MM_UNROLL " << ks.unroll << "\n";
         out << device_prelude() << "\n";
         if (uses_noise(code.body)) {
             if (!noise_table_text())
@@ -432,20 +488,71 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
   const int swz = xcd * per + (xcd < rem ? xcd : rem) + q;
   const int tile_y = swz / tiles_x, tile_x = swz - tile_y * tiles_x;
   const int col = tile_x * MM_TILE_W + (threadIdx.x % MM_TILE_W);
-  const int rl = tile_y * MM_TILE_H + (threadIdx.x / MM_TILE_W);   // row within this launch
-  if (col >= A.region_width || rl >= A.num_rows) return;
-  const float y = A.ytab[rl];    // CALC_VIRTUAL_Y(first_row + rl, ...), computed once per row by the prologue
+  // a workgroup owns MM_TILE_W x (MM_TILE_H * A.ppt) pixels; each work-item walks A.ppt rows
+  // MM_TILE_H apart, so wave start-up (kernarg / descriptor loads, tile arithmetic) and the
+  // dispatcher's per-workgroup cost are paid once per A.ppt pixels
+  const int row0 = tile_y * (MM_TILE_H * A.ppt) + (threadIdx.x / MM_TILE_W);   // row within this launch
+  if (col >= A.region_width) return;
   const float x = A.xtab[col];   // CALC_VIRTUAL_X(col + region_x, ...), once per column
-  (void)x; (void)y;
+  (void)x;
 )";
         for (Value *v : transfer_order)
             out << "  const " << ctype(v->var) << " " << vname(v) << " = *(const " << ctype(v->var) << " *)(XY + "
                 << transfer_off[v] << ");\n";
-        decls(pix_defs, "  ");
-        stmts(code.body, PIXEL, "  ");
-        out << "  mm_tup<4> rt;\n";
-        for (int i = 0; i < 4; ++i) out << "  rt.v[" << i << "] = " << prim(Primary::V(code.result[i]), PIXEL) << ";\n";
-        out << "  mm_store_pixel(A, rl, col, rt);\n}\n";
+        // descriptors of frame-constant images, loaded (scalar) once before the pixel loop
+        for (Value *v : transfer_order)
+            if (v->var->type == Ty::Image) {
+                out << "  const mm_image_desc " << vname(v) << "_desc = mm_load_desc(A, " << vname(v) << ");\n";
+                preloaded_desc.insert(v);
+            }
+        // MM_UNROLL pixels are evaluated back to back before any of them is stored: with the
+        // branch-free fetch their image loads are independent and overlap (one load per wave in
+        // flight cannot cover HBM latency); rows past the end are computed on the last row and
+        // simply not stored.  A.ppt is a multiple of MM_UNROLL (runtime.cpp).
+        auto emit_loop = [&](const char *ind) {
+            std::string I = ind;
+            out << "#pragma unroll 1\n" << I << "for (int mm_p = 0; mm_p < A.ppt; mm_p += MM_UNROLL) {\n"
+                << I << "  mm_tup<4> mm_rt[MM_UNROLL];\n"
+                << I << "  float mm_y[MM_UNROLL];\n"
+                << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {   // all row coordinates first: one wait\n"
+                << I << "    const int rl_raw = row0 + (mm_p + mm_u) * MM_TILE_H;\n"
+                << I << "    mm_y[mm_u] = A.ytab[rl_raw < A.num_rows ? rl_raw : A.num_rows - 1];\n"
+                << I << "  }\n"
+                << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
+                << I << "    const float y = mm_y[mm_u];    // CALC_VIRTUAL_Y(first_row + rl, ...), once per row by the prologue\n"
+                << I << "    (void)y;\n";
+            decls(pix_defs, (I + "    ").c_str());
+            stmts(code.body, PIXEL, (I + "    ").c_str());
+            for (int i = 0; i < 4; ++i)
+                out << I << "    mm_rt[mm_u].v[" << i << "] = " << prim(Primary::V(code.result[i]), PIXEL) << ";\n";
+            out << I << "  }\n#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
+                << I << "    // a row past the end was evaluated as the last row: storing it there again writes the\n"
+                << I << "    // same bytes, and keeps the pixel bodies free of a store guard the compiler would\n"
+                << I << "    // otherwise sink them (and their loads) into\n"
+                << I << "    const int rl_raw = row0 + (mm_p + mm_u) * MM_TILE_H;\n"
+                << I << "    mm_store_pixel(A, rl_raw < A.num_rows ? rl_raw : A.num_rows - 1, col, mm_rt[mm_u]);\n" << I << "  }\n" << I << "}\n";
+        };
+        // Hot variant: when every fetch through a preloaded descriptor reads a bound drawable
+        // at a valid, frame-constant frame number (true for every ordinary render), those
+        // conditions -- all wave-uniform -- are tested once here instead of inside each fetch,
+        // which leaves the unrolled pixel bodies free of branches.
+        std::vector<std::string> hot_conds;
+        find_hot_fetches(code.body, hot_conds);
+        if (ks.unroll > 1 && !hot_conds.empty()) {
+            out << "  bool mm_hot = true;\n";
+            for (const std::string &c : hot_conds) out << "  mm_hot = mm_hot && " << c << ";\n";
+            out << "  if (mm_hot) {\n";
+            hot_mode = true;
+            emit_loop("    ");
+            hot_mode = false;
+            out << "  } else {\n";
+            emit_loop("    ");
+            out << "  }\n";
+        } else {
+            hot_sites.clear();
+            emit_loop("  ");
+        }
+        out << "}\n";
         ks.source = out.str();
         char buf[32];
         snprintf(buf, sizeof buf, "%016llx", fnv(ks.source));

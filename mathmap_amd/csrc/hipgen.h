@@ -13,6 +13,7 @@ struct KernelOptions {
     int supersampling = 0;
     int edge_x = 0, edge_y = 0;
     int tile_w = 16;          // pixels per workgroup row; tile_h = 256 / tile_w
+    int unroll = 0;           // pixels evaluated back to back per work-item step; 0 = choose (hipgen.cpp auto_unroll)
     bool hoist = true;        // evaluate frame-constant code once per frame in a prologue kernel
     bool fast_math_exact = true;   // use f32 paths only where bit-identical to the double path
 };
@@ -33,6 +34,7 @@ struct KernelSource {
     bool has_prologue = false;
     std::vector<NativeCall> natives;
     int tile_w = 16, tile_h = 16;
+    int unroll = 1;               // MM_UNROLL of the pixel kernel; the launch's rows per work-item is a multiple
     std::string key;              // cache key (hash of source)
 };
 

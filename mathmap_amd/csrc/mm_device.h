@@ -80,7 +80,7 @@ struct mm_args {
     const void *gradients;            // color_t[n][1024]
     void *out;
     int native_slot_base;             // image-table index of native-filter result 0
-    int pad0;
+    int ppt;                          // pixels (rows, MM_TILE_H apart) each work-item renders
     // per-column x and per-row y virtual coordinates of this launch, filled by the
     // prologue kernel (the reference's y_vars / per-row x-const code,
     // new_template.c.in:245,260,357-372): the double divide is done once per row and
@@ -372,15 +372,40 @@ MM_DEV void mm_apply_edge_behaviour(int &x, int &y, int width, int height) {
 #endif
 }
 
-MM_DEV color_t mm_get_pixel(const mm_args &A, const mm_image_desc &d, int x, int y, int frame) {
+// Image data lives in HBM: say so, so the loads are global_load (vmcnt only) instead of flat.
+typedef const __attribute__((address_space(1))) color_t *mm_gpix;
+typedef const __attribute__((address_space(1))) float4 *mm_gmap;
+
+// get_pixel (mathmap_cmdline.c:131-184 / mathmap.c:1195-1209).
+// Hot variant: `d` is a bound drawable and `frame` is valid (both wave-uniform, tested once by
+// the caller).  Written without branches: the texel is always loaded from the clamped
+// coordinates (in bounds for any bound image) and the edge colours are selected afterwards,
+// so the taps of a fetch -- and of the next unrolled pixel -- form one basic block and their
+// loads are in flight together.
+MM_DEV color_t mm_get_pixel(const mm_args &A, const mm_image_desc &d, int x, int y) {
+    mm_apply_edge_behaviour(x, y, d.w, d.h);
+    const bool out_x = x < 0 || x >= d.w, out_y = y < 0 || y >= d.h;
+    const int cx = x < 0 ? 0 : (x >= d.w ? d.w - 1 : x), cy = y < 0 ? 0 : (y >= d.h ? d.h - 1 : y);
+    color_t v = ((mm_gpix)d.data)[(long)cy * d.w + cx];
+    if (out_y) v = A.edge_color_y;
+    if (out_x) v = A.edge_color_x;
+    return v;
+}
+// General variant (unbound image or frame out of range): the reference's order of tests.
+MM_DEV color_t mm_get_pixel_cold(const mm_args &A, const mm_image_desc &d, int x, int y, int frame) {
     if (d.kind == MM_IMG_NULL) return MAKE_RGBA_COLOR(255, 255, 255, 255);
     mm_apply_edge_behaviour(x, y, d.w, d.h);
     if (x < 0 || x >= d.w) return A.edge_color_x;
     if (y < 0 || y >= d.h) return A.edge_color_y;
     if (frame < 0 || frame >= d.num_frames) return MAKE_RGBA_COLOR(255, 255, 255, 255);
-    return ((const color_t *)d.data)[(long)y * d.w + x];
+    return ((mm_gpix)d.data)[(long)y * d.w + x];
+}
+MM_DEV bool mm_fetch_is_hot(const mm_image_desc &d, int frame) {
+    return d.kind == MM_IMG_DRAWABLE && frame >= 0 && frame < d.num_frames;
 }
 
+// HOT: the caller has established mm_fetch_is_hot(d, frame) for the whole launch.
+template <bool HOT>
 MM_DEV color_t mm_orig_val_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
@@ -392,9 +417,11 @@ MM_DEV color_t mm_orig_val_pixel(const mm_args &A, const mm_image_desc &d, float
     y = y + 0.5f;
 #endif
     // floor((double)x) of a float is the float floor: identical integer
-    return mm_get_pixel(A, d, (int)floorf(x), (int)floorf(y), frame);
+    if (HOT || mm_fetch_is_hot(d, frame)) return mm_get_pixel(A, d, (int)floorf(x), (int)floorf(y));
+    return mm_get_pixel_cold(A, d, (int)floorf(x), (int)floorf(y), frame);
 }
 
+template <bool HOT>
 MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
@@ -405,8 +432,18 @@ MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_de
     // so this is the correctly rounded float subtraction
     float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
     float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
-    color_t p1 = mm_get_pixel(A, d, x1, y1, frame), p2 = mm_get_pixel(A, d, x1, y2, frame);
-    color_t p3 = mm_get_pixel(A, d, x2, y1, frame), p4 = mm_get_pixel(A, d, x2, y2, frame);
+    color_t p1, p2, p3, p4;
+    if (HOT || mm_fetch_is_hot(d, frame)) {      // wave-uniform
+        p1 = mm_get_pixel(A, d, x1, y1);
+        p2 = mm_get_pixel(A, d, x1, y2);
+        p3 = mm_get_pixel(A, d, x2, y1);
+        p4 = mm_get_pixel(A, d, x2, y2);
+    } else {
+        p1 = mm_get_pixel_cold(A, d, x1, y1, frame);
+        p2 = mm_get_pixel_cold(A, d, x1, y2, frame);
+        p3 = mm_get_pixel_cold(A, d, x2, y1, frame);
+        p4 = mm_get_pixel_cold(A, d, x2, y2, frame);
+    }
     float r = RED(p1) * p1fact, g = GREEN(p1) * p1fact, b = BLUE(p1) * p1fact, a = ALPHA(p1) * p1fact;
     r = r + RED(p2) * p2fact; g = g + GREEN(p2) * p2fact; b = b + BLUE(p2) * p2fact; a = a + ALPHA(p2) * p2fact;
     r = r + RED(p3) * p3fact; g = g + GREEN(p3) * p3fact; b = b + BLUE(p3) * p3fact; a = a + ALPHA(p3) * p3fact;
@@ -419,26 +456,57 @@ MM_DEV mm_tup<4> mm_floatmap_pixel(const mm_image_desc &d, float x, float y) {
     mm_tup<4> t;
     int ix = (int)lrintf(d.ax * x + d.bx);
     int iy = (int)lrintf(d.ay * y + d.by);
-    if (ix < 0 || ix >= d.w || iy < 0 || iy >= d.h) {
-        t.v[0] = t.v[1] = t.v[2] = t.v[3] = 0.0f;
-        return t;
-    }
-    const float4 p = ((const float4 *)d.data)[(long)iy * d.w + ix];
-    t.v[0] = p.x; t.v[1] = p.y; t.v[2] = p.z; t.v[3] = p.w;
+    const bool outside = ix < 0 || ix >= d.w || iy < 0 || iy >= d.h;
+    const int cx = ix < 0 ? 0 : (ix >= d.w ? d.w - 1 : ix), cy = iy < 0 ? 0 : (iy >= d.h ? d.h - 1 : iy);
+    const float4 p = ((mm_gmap)d.data)[(long)cy * d.w + cx];
+    t.v[0] = outside ? 0.0f : p.x; t.v[1] = outside ? 0.0f : p.y;
+    t.v[2] = outside ? 0.0f : p.z; t.v[3] = outside ? 0.0f : p.w;
     return t;
 }
 
+// The descriptor of an image value.  For frame-constant images the generated kernel calls
+// this once per work-item, before the pixel loop: after the first store of the loop the
+// compiler may no longer use scalar loads for it.
+MM_DEV mm_image_desc mm_load_desc(const mm_args &A, mm_image img) {
+    if (img.idx < 0) {
+        mm_image_desc d;
+        d.data = nullptr;
+        d.w = d.h = 0;
+        d.kind = MM_IMG_NULL;
+        d.num_frames = 0;
+        d.scale_x = d.scale_y = d.middle_x = d.middle_y = 0.0f;
+        d.ax = d.bx = d.ay = d.by = 0.0f;
+        return d;
+    }
+    return A.images[img.idx];
+}
+
 // opmacros.h:199-216 (closure images are applied at compile time and never reach here)
-MM_DEV mm_tup<4> mm_orig_val(const mm_args &A, float x, float y, mm_image img, float f) {
+MM_DEV mm_tup<4> mm_orig_val_d(const mm_args &A, float x, float y, mm_image img, float f, const mm_image_desc &d) {
     if (img.resized) { x *= img.xf; y *= img.yf; }
     if (img.idx < 0) { mm_tup<4> t; t.v[0] = t.v[1] = t.v[2] = t.v[3] = 1.0f; return t; }
-    const mm_image_desc &d = A.images[img.idx];
     if (d.kind == MM_IMG_FLOATMAP) return mm_floatmap_pixel(d, x, y);
 #if MM_INTERSAMPLE
-    return mm_tuple_from_color(mm_orig_val_intersample_pixel(A, d, x, y, (int)f));
+    return mm_tuple_from_color(mm_orig_val_intersample_pixel<false>(A, d, x, y, (int)f));
 #else
-    return mm_tuple_from_color(mm_orig_val_pixel(A, d, x, y, (int)f));
+    return mm_tuple_from_color(mm_orig_val_pixel<false>(A, d, x, y, (int)f));
 #endif
+}
+// The fetch of the kernel's hot variant: the image is a bound drawable and the frame valid
+// (checked once per work-item before the pixel loop), so nothing here branches and the loads
+// of consecutive unrolled pixels can overlap.  x * 1.0f is x, so the resize factors are
+// applied by multiplication with a selected factor instead of under `if (img.resized)`.
+MM_DEV mm_tup<4> mm_orig_val_hot(const mm_args &A, float x, float y, mm_image img, const mm_image_desc &d) {
+    x *= img.resized ? img.xf : 1.0f;
+    y *= img.resized ? img.yf : 1.0f;
+#if MM_INTERSAMPLE
+    return mm_tuple_from_color(mm_orig_val_intersample_pixel<true>(A, d, x, y, 0));
+#else
+    return mm_tuple_from_color(mm_orig_val_pixel<true>(A, d, x, y, 0));
+#endif
+}
+MM_DEV mm_tup<4> mm_orig_val(const mm_args &A, float x, float y, mm_image img, float f) {
+    return mm_orig_val_d(A, x, y, img, f, mm_load_desc(A, img));
 }
 #define ORIG_VAL(x, y, i, f) (mm_orig_val(A, (x), (y), (i), (f)))
 

@@ -42,7 +42,7 @@ struct HArgs {
     const void *gradients;
     void *out;
     int native_slot_base;
-    int pad0;
+    int ppt;
     float *xtab;
     float *ytab;
 };

@@ -624,7 +624,15 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
         if (!f->ks.natives.empty() && run_natives(inv, a, s) != 0) return -1;
     }
     int tiles_x = (region_w + f->ks.tile_w - 1) / f->ks.tile_w;
-    int tiles_y = (a.num_rows + f->ks.tile_h - 1) / f->ks.tile_h;
+    // rows per work-item: enough workgroups must remain to fill 256 CUs several times over
+    {
+        const long wg1 = (long)tiles_x * ((a.num_rows + f->ks.tile_h - 1) / f->ks.tile_h);
+        int ppt = wg1 >= 32768 ? 4 : wg1 >= 8192 ? 2 : 1;
+        if (const char *e = getenv("MMHIP_PPT")) ppt = std::max(1, atoi(e));
+        const int u = std::max(1, f->ks.unroll);          // the kernel steps MM_UNROLL rows at a time
+        a.ppt = (ppt + u - 1) / u * u;
+    }
+    int tiles_y = (a.num_rows + f->ks.tile_h * a.ppt - 1) / (f->ks.tile_h * a.ppt);
     long nwg = (long)tiles_x * tiles_y;
     if (nwg > 0x7fffffffL) return fail("region too large for one launch");
     if (inv->timing) HIP_TRY(hipEventRecord(inv->ev0, s));
