@@ -499,6 +499,30 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         for (Value *v : transfer_order)
             out << "  const " << ctype(v->var) << " " << vname(v) << " = *(const " << ctype(v->var) << " *)(XY + "
                 << transfer_off[v] << ");\n";
+        // Large bodies keep the one-pixel-per-work-item shape: a pixel loop makes every frame
+        // constant live across it in SGPRs (after the loop's first store the compiler may not
+        // re-issue scalar loads), and Droste's ~60 of them spilled to VGPR lanes -- 1.7x slower.
+        // Such kernels are compute-bound; the per-workgroup dispatch cost does not show.
+        {
+            int stmts = 0, fetches = 0;
+            pixel_stats(code.body, stmts, fetches);
+            ks.single_pixel = stmts > 400 || transfer_order.size() > 24;
+            if (const char *e = getenv("MMHIP_SINGLE_PIXEL")) ks.single_pixel = atoi(e) != 0;
+        }
+        if (ks.single_pixel) {
+            ks.unroll = 1;
+            out << "  const int rl = row0;   // A.ppt is 1 for this kernel (KernelSource::single_pixel)\n"
+                   "  if (rl >= A.num_rows) return;\n"
+                   "  const float y = A.ytab[rl];    // CALC_VIRTUAL_Y(first_row + rl, ...), once per row by the prologue\n"
+                   "  (void)y;\n";
+            decls(pix_defs, "  ");
+            stmts(code.body, PIXEL, "  ");
+            out << "  mm_tup<4> rt;\n";
+            for (int i = 0; i < 4; ++i) out << "  rt.v[" << i << "] = " << prim(Primary::V(code.result[i]), PIXEL) << ";\n";
+            out << "  mm_store_pixel(A, rl, col, rt);\n}\n";
+            finish_source();
+            return;
+        }
         // descriptors of frame-constant images, loaded (scalar) once before the pixel loop
         for (Value *v : transfer_order)
             if (v->var->type == Ty::Image) {
@@ -553,6 +577,10 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
             emit_loop("  ");
         }
         out << "}\n";
+        finish_source();
+    }
+
+    void finish_source() {
         ks.source = out.str();
         char buf[32];
         snprintf(buf, sizeof buf, "%016llx", fnv(ks.source));

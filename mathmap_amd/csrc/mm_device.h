@@ -376,6 +376,14 @@ MM_DEV void mm_apply_edge_behaviour(int &x, int &y, int width, int height) {
 typedef const __attribute__((address_space(1))) color_t *mm_gpix;
 typedef const __attribute__((address_space(1))) float4 *mm_gmap;
 
+// Texel (cx, cy) of a hot image, in range.  mm_fetch_is_hot guarantees w, h < 2^24 and
+// 4*w*h < 2^32, so the byte offset is one 24-bit multiply-add in 32 bits and the load takes
+// the scalar base + 32-bit vector offset form (no 64-bit address arithmetic per tap).
+MM_DEV color_t mm_load_texel(const mm_image_desc &d, int cx, int cy) {
+    const unsigned boff = (__umul24((unsigned)cy, (unsigned)d.w) + (unsigned)cx) << 2;
+    return *(mm_gpix)((const __attribute__((address_space(1))) char *)d.data + boff);
+}
+
 // get_pixel (mathmap_cmdline.c:131-184 / mathmap.c:1195-1209).
 // Hot variant: `d` is a bound drawable and `frame` is valid (both wave-uniform, tested once by
 // the caller).  Written without branches: the texel is always loaded from the clamped
@@ -386,12 +394,15 @@ MM_DEV color_t mm_get_pixel(const mm_args &A, const mm_image_desc &d, int x, int
     mm_apply_edge_behaviour(x, y, d.w, d.h);
     const bool out_x = x < 0 || x >= d.w, out_y = y < 0 || y >= d.h;
     const int cx = x < 0 ? 0 : (x >= d.w ? d.w - 1 : x), cy = y < 0 ? 0 : (y >= d.h ? d.h - 1 : y);
-    color_t v = ((mm_gpix)d.data)[(long)cy * d.w + cx];
+    color_t v = mm_load_texel(d, cx, cy);
     if (out_y) v = A.edge_color_y;
     if (out_x) v = A.edge_color_x;
     return v;
 }
-// General variant (unbound image or frame out of range): the reference's order of tests.
+// General variant: the reference's order of tests, each an early exit.  Besides unbound images
+// and odd frame numbers this is also what large filter bodies use (no hot variant is built for
+// them): a wave whose lanes all sample outside the image -- most of Droste's outer levels --
+// then issues no load at all, which beats the branch-free form there.
 MM_DEV color_t mm_get_pixel_cold(const mm_args &A, const mm_image_desc &d, int x, int y, int frame) {
     if (d.kind == MM_IMG_NULL) return MAKE_RGBA_COLOR(255, 255, 255, 255);
     mm_apply_edge_behaviour(x, y, d.w, d.h);
@@ -401,7 +412,8 @@ MM_DEV color_t mm_get_pixel_cold(const mm_args &A, const mm_image_desc &d, int x
     return ((mm_gpix)d.data)[(long)y * d.w + x];
 }
 MM_DEV bool mm_fetch_is_hot(const mm_image_desc &d, int frame) {
-    return d.kind == MM_IMG_DRAWABLE && frame >= 0 && frame < d.num_frames;
+    return d.kind == MM_IMG_DRAWABLE && frame >= 0 && frame < d.num_frames && d.w < (1 << 24) && d.h < (1 << 24) &&
+           (long)d.w * d.h < (1L << 30);
 }
 
 // HOT: the caller has established mm_fetch_is_hot(d, frame) for the whole launch.
@@ -417,7 +429,7 @@ MM_DEV color_t mm_orig_val_pixel(const mm_args &A, const mm_image_desc &d, float
     y = y + 0.5f;
 #endif
     // floor((double)x) of a float is the float floor: identical integer
-    if (HOT || mm_fetch_is_hot(d, frame)) return mm_get_pixel(A, d, (int)floorf(x), (int)floorf(y));
+    if (HOT) return mm_get_pixel(A, d, (int)floorf(x), (int)floorf(y));
     return mm_get_pixel_cold(A, d, (int)floorf(x), (int)floorf(y), frame);
 }
 
@@ -433,7 +445,7 @@ MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_de
     float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
     float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
     color_t p1, p2, p3, p4;
-    if (HOT || mm_fetch_is_hot(d, frame)) {      // wave-uniform
+    if (HOT) {
         p1 = mm_get_pixel(A, d, x1, y1);
         p2 = mm_get_pixel(A, d, x1, y2);
         p3 = mm_get_pixel(A, d, x2, y1);
@@ -496,11 +508,54 @@ MM_DEV mm_tup<4> mm_orig_val_d(const mm_args &A, float x, float y, mm_image img,
 // (checked once per work-item before the pixel loop), so nothing here branches and the loads
 // of consecutive unrolled pixels can overlap.  x * 1.0f is x, so the resize factors are
 // applied by multiplication with a selected factor instead of under `if (img.resized)`.
+typedef float mm_f2 __attribute__((ext_vector_type(2)));
+
+// k / 255 for an integer-valued float k in [0, 255], two channels at a time: bit-identical to
+// MM_BYTE_TO_UNIT's (float)((double)k * (1.0 / 255.0)) -- both are the correctly rounded
+// quotient (enumerated for all 256 values, tests/test_cpu_suite.py) -- by one Newton step on
+// the f32 product: q = k*r, q' = q + (k - 255 q) r with the residual exact in an fma.
+MM_DEV mm_f2 mm_bytes_to_unit(mm_f2 k) {
+    const float r = 1.0f / 255.0f;
+    const mm_f2 q = k * r;
+    const mm_f2 e = __builtin_elementwise_fma(mm_f2{-255.0f, -255.0f}, q, k);
+    return __builtin_elementwise_fma(e, mm_f2{r, r}, q);
+}
+
+// get_orig_val_intersample_pixel + TUPLE_FROM_COLOR for a hot image, fused: same operations
+// in the same order per channel (builtins.c:202-250), two channels per packed instruction;
+// the rounded channel value stays a float ((color_t)rintf(v) & 0xff is rintf(v) for the
+// [0, 255.5) a convex combination of bytes lies in; v_med3 keeps wild coordinates in range).
+MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc &d, float x, float y) {
+    x = (x + d.middle_x) * d.scale_x;
+    y = -((y - d.middle_y) * d.scale_y);
+    const int x1 = (int)floorf(x), x2 = x1 + 1;
+    const int y1 = (int)floorf(y), y2 = y1 + 1;
+    const float x2fact = x - x1, y2fact = y - y1;
+    const float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
+    const float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
+    const color_t p1 = mm_get_pixel(A, d, x1, y1), p2 = mm_get_pixel(A, d, x1, y2);
+    const color_t p3 = mm_get_pixel(A, d, x2, y1), p4 = mm_get_pixel(A, d, x2, y2);
+    mm_f2 rg = mm_f2{(float)RED(p1), (float)GREEN(p1)} * p1fact, ba = mm_f2{(float)BLUE(p1), (float)ALPHA(p1)} * p1fact;
+    rg = rg + mm_f2{(float)RED(p2), (float)GREEN(p2)} * p2fact;
+    ba = ba + mm_f2{(float)BLUE(p2), (float)ALPHA(p2)} * p2fact;
+    rg = rg + mm_f2{(float)RED(p3), (float)GREEN(p3)} * p3fact;
+    ba = ba + mm_f2{(float)BLUE(p3), (float)ALPHA(p3)} * p3fact;
+    rg = rg + mm_f2{(float)RED(p4), (float)GREEN(p4)} * p4fact;
+    ba = ba + mm_f2{(float)BLUE(p4), (float)ALPHA(p4)} * p4fact;
+    rg = mm_f2{__builtin_amdgcn_fmed3f(rintf(rg.x), 0.0f, 255.0f), __builtin_amdgcn_fmed3f(rintf(rg.y), 0.0f, 255.0f)};
+    ba = mm_f2{__builtin_amdgcn_fmed3f(rintf(ba.x), 0.0f, 255.0f), __builtin_amdgcn_fmed3f(rintf(ba.y), 0.0f, 255.0f)};
+    rg = mm_bytes_to_unit(rg);
+    ba = mm_bytes_to_unit(ba);
+    mm_tup<4> t;
+    t.v[0] = rg.x; t.v[1] = rg.y; t.v[2] = ba.x; t.v[3] = ba.y;
+    return t;
+}
+
 MM_DEV mm_tup<4> mm_orig_val_hot(const mm_args &A, float x, float y, mm_image img, const mm_image_desc &d) {
     x *= img.resized ? img.xf : 1.0f;
     y *= img.resized ? img.yf : 1.0f;
 #if MM_INTERSAMPLE
-    return mm_tuple_from_color(mm_orig_val_intersample_pixel<true>(A, d, x, y, 0));
+    return mm_intersample_tuple_hot(A, d, x, y);
 #else
     return mm_tuple_from_color(mm_orig_val_pixel<true>(A, d, x, y, 0));
 #endif
@@ -514,6 +569,11 @@ MM_DEV mm_tup<4> mm_orig_val(const mm_args &A, float x, float y, mm_image img, f
 #define CALC_VIRTUAL_X(pxl, size, off) (((pxl) - ((size)-1) / 2.0 + (off)) / (((size)-1) / 2.0))
 #define CALC_VIRTUAL_Y(pxl, size, off) ((-(pxl) + ((size)-1) / 2.0 - (off)) / (((size)-1) / 2.0))
 
+// CLAMP01 for the pack: MAX(0, MIN(1, x)) sends NaN to 0, and so does v_med3_f32 (with a NaN
+// operand it returns the minimum of the others); the sign of a zero result is not observable
+// after the multiply and the conversion to a byte.
+MM_DEV float mm_clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+
 MM_DEV void mm_store_pixel(const mm_args &A, int row_in_launch, int col, const mm_tup<4> &rt) {
     if (A.floatmap) {
         float4 *o = (float4 *)A.out + (long)row_in_launch * A.frame_render_width + col;
@@ -522,21 +582,22 @@ MM_DEV void mm_store_pixel(const mm_args &A, int row_in_launch, int col, const m
     }
     unsigned char *p = (unsigned char *)A.out + (long)row_in_launch * A.row_stride + (long)col * A.output_bpp;
     const int bpp = A.output_bpp;
+    // new_template.c.in:279-293: the products are double, the conversion to a byte truncates
     if (bpp == 4) {
         // one aligned 32-bit store: bytes R,G,B,A in memory order
-        unsigned r = (unsigned char)(CLAMP01(rt.v[0]) * 255.0), g = (unsigned char)(CLAMP01(rt.v[1]) * 255.0);
-        unsigned b = (unsigned char)(CLAMP01(rt.v[2]) * 255.0), a = (unsigned char)(CLAMP01(rt.v[3]) * 255.0);
+        const unsigned r = (unsigned char)(mm_clamp01(rt.v[0]) * 255.0), g = (unsigned char)(mm_clamp01(rt.v[1]) * 255.0);
+        const unsigned b = (unsigned char)(mm_clamp01(rt.v[2]) * 255.0), a = (unsigned char)(mm_clamp01(rt.v[3]) * 255.0);
         *(unsigned *)p = r | (g << 8) | (b << 16) | (a << 24);
         return;
     }
     if (bpp == 1 || bpp == 2)
-        p[0] = (CLAMP01(rt.v[0]) * 0.299 + CLAMP01(rt.v[1]) * 0.587 + CLAMP01(rt.v[2]) * 0.114) * 255.0;
+        p[0] = (mm_clamp01(rt.v[0]) * 0.299 + mm_clamp01(rt.v[1]) * 0.587 + mm_clamp01(rt.v[2]) * 0.114) * 255.0;
     else {
-        p[0] = CLAMP01(rt.v[0]) * 255.0;
-        p[1] = CLAMP01(rt.v[1]) * 255.0;
-        p[2] = CLAMP01(rt.v[2]) * 255.0;
+        p[0] = mm_clamp01(rt.v[0]) * 255.0;
+        p[1] = mm_clamp01(rt.v[1]) * 255.0;
+        p[2] = mm_clamp01(rt.v[2]) * 255.0;
     }
-    if (bpp == 2 || bpp == 4) p[bpp - 1] = CLAMP01(rt.v[3]) * 255.0;
+    if (bpp == 2 || bpp == 4) p[bpp - 1] = mm_clamp01(rt.v[3]) * 255.0;
 }
 
 #endif  // MM_DEVICE_H

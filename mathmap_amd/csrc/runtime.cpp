@@ -627,8 +627,9 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     // rows per work-item: enough workgroups must remain to fill 256 CUs several times over
     {
         const long wg1 = (long)tiles_x * ((a.num_rows + f->ks.tile_h - 1) / f->ks.tile_h);
-        int ppt = wg1 >= 32768 ? 4 : wg1 >= 8192 ? 2 : 1;
+        int ppt = wg1 >= 131072 ? 8 : wg1 >= 32768 ? 4 : wg1 >= 8192 ? 2 : 1;
         if (const char *e = getenv("MMHIP_PPT")) ppt = std::max(1, atoi(e));
+        if (f->ks.single_pixel) ppt = 1;
         const int u = std::max(1, f->ks.unroll);          // the kernel steps MM_UNROLL rows at a time
         a.ppt = (ppt + u - 1) / u * u;
     }

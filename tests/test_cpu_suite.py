@@ -269,6 +269,21 @@ def test_byte_to_float_identity():
     assert np.array_equal((c / 255.0).astype(np.float32), (c * (1.0 / 255.0)).astype(np.float32))
 
 
+def test_byte_to_unit_newton_step_identity():
+    """mm_bytes_to_unit (mm_device.h): q = k*r, e = fma(-255, q, k), q' = fma(e, r, q) in f32 equals
+    (float)((double)k * (1.0/255.0)) for every byte k.  The fmas are emulated exactly: 255*q has at
+    most 32 significant bits and the residual 8, so float64 arithmetic reproduces them."""
+    k = np.arange(256, dtype=np.float32)
+    r = np.float32(1.0) / np.float32(255.0)
+    q = (k * r).astype(np.float32)
+    e = (k.astype(np.float64) - 255.0 * q.astype(np.float64))          # exact
+    assert np.array_equal(e.astype(np.float32).astype(np.float64), e)   # representable: the fma is exact
+    q2 = (q.astype(np.float64) + e * np.float64(r)).astype(np.float32)  # one rounding, like the fma
+    want = (k.astype(np.float64) * (1.0 / 255.0)).astype(np.float32)
+    assert np.array_equal(q2, want)
+    assert (q != want).any()       # the plain f32 product alone is NOT enough
+
+
 def test_sqrt_less_power_of_two_identity():
     """sqrt_rn(a) < K  <=>  0 <= a < K*K for K a power of two, checked on every float in a
     window of +-2^16 ulps around K*K and on random floats."""
