@@ -177,7 +177,13 @@ struct Generator {
                     if (pow2 && d && d->kind == Stmt::Assign && d->rhs.kind == Rhs::Op && !strcmp(d->rhs.op->cname, "sqrt") &&
                         d->lhs->var->type == Ty::Float && d->rhs.args[0].type() == Ty::Float &&
                         d->rhs.args[0].kind == Primary::Val && value_visible(d->rhs.args[0].value, sl))
+                    {
+                        // a sum of float squares is >= +0 or NaN, and `a < K*K` is false for NaN like
+                        // sqrt(NaN) < K: the `a >= 0` half of the test is then dead
+                        if (nonneg_or_nan(d->rhs.args[0].value, 0))
+                            return "((" + prim(d->rhs.args[0], sl) + ") < " + float_literal((float)(k * k)) + "f)";
                         return "MM_SQRT_LESS_POW2(" + prim(d->rhs.args[0], sl) + ", " + float_literal((float)(k * k)) + "f)";
+                    }
                 }
                 if (sl == PIXEL && hot_mode && hot_sites.count(stmt))
                     return "mm_orig_val_hot(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " + prim(r.args[2], sl) +
@@ -235,6 +241,29 @@ struct Generator {
             if (s->kind == Stmt::If && (uses_noise(s->then_) || uses_noise(s->else_))) return true;
             if (s->kind == Stmt::While && uses_noise(s->body)) return true;
         }
+        return false;
+    }
+
+    // Is the float value provably >= +0 (or NaN)?  Squares of one value, non-negative literals,
+    // and sums / copies of such.  Products and sums are f32 here (the C type of float (op) float
+    // is promoted to double by the op macros only for libm calls, not for + and *).
+    static bool nonneg_or_nan(const Value *v, int depth) {
+        if (!v || depth > 16 || v->var->type != Ty::Float) return false;
+        const Stmt *d = v->def;
+        if (!d || d->kind != Stmt::Assign) return false;
+        const Rhs &r = d->rhs;
+        auto prim_ok = [&](const Primary &p) {
+            if (p.kind == Primary::FloatConst) return p.f >= 0.0f && !std::signbit(p.f);
+            if (p.kind == Primary::IntConst) return p.i >= 0;
+            if (p.kind == Primary::Val) return nonneg_or_nan(p.value, depth + 1);
+            return false;
+        };
+        if (r.kind == Rhs::Prim) return prim_ok(r.prim);
+        if (r.kind != Rhs::Op) return false;
+        if (!strcmp(r.op->cname, "MUL") && r.args.size() == 2 && r.args[0].kind == Primary::Val && r.args[1].kind == Primary::Val &&
+            r.args[0].value == r.args[1].value && r.args[0].value->var->type == Ty::Float)
+            return true;
+        if (!strcmp(r.op->cname, "ADD") && r.args.size() == 2) return prim_ok(r.args[0]) && prim_ok(r.args[1]);
         return false;
     }
 

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -192,7 +193,14 @@ long mmhip_filter_jit(mmhip_filter *f, int load_module) {
     if (f->deferred) return 0;     // kernels are built per user-value set at render time
     auto t0 = std::chrono::steady_clock::now();
     if (f->code_object.empty()) {
-        std::string path = cache_dir() + "/" + f->ks.key + ".hsaco";
+        // extra hiprtc options for experiments (space separated); part of the cache key
+        std::vector<std::string> extra;
+        std::string extra_key;
+        if (const char *e = getenv("MMHIP_HIPRTC_FLAGS")) {
+            std::istringstream is(e);
+            for (std::string w; is >> w;) { extra.push_back(w); extra_key += "_" + std::to_string(std::hash<std::string>()(w) & 0xffff); }
+        }
+        std::string path = cache_dir() + "/" + f->ks.key + extra_key + ".hsaco";
         std::ifstream in(path, std::ios::binary);
         if (in && !getenv("MMHIP_NO_CACHE")) {
             f->code_object.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
@@ -201,8 +209,9 @@ long mmhip_filter_jit(mmhip_filter *f, int load_module) {
             hiprtcProgram prog;
             if (hiprtcCreateProgram(&prog, f->ks.source.c_str(), "mathmap_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
                 return fail("hiprtcCreateProgram failed");
-            const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
-            hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+            std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+            for (const std::string &w : extra) opts.push_back(w.c_str());
+            hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
             if (r != HIPRTC_SUCCESS) {
                 size_t n = 0;
                 hiprtcGetProgramLogSize(prog, &n);
