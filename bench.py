@@ -139,7 +139,9 @@ def main():
                        "jit_seconds": round(jit_s, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mm_pixels", "kernel_ms": k_ms, "algorithmic_bytes_per_pixel": bpp},
+                         "kernel": "gaussian_blur chain: k_render_drawable + 2x(k_iir_causal, k_iir_anticausal_T) + mm_pixels"
+                         if args.workload == "gauss" else "mm_pixels",
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_pixel": bpp},
         }
         if args.workload == "mandelbrot":
             # compute-side view (the kernel writes 4 B/px and reads nothing, so HBM is not its
@@ -149,7 +151,7 @@ def main():
             res["valu"] = {"pixel_iterations_per_launch": n_iter, "useful_flops_per_launch": flops,
                            "achieved_tflops": flops / (k_ms * 1e-3) / 1e12, "peak_tflops_f32_no_fma": 78.6,
                            "note": "exact-rounding code cannot use FMA, so the peak is half the 157.3 TF vector peak"}
-        if world == 1 and args.specialize and not args.no_generic:
+        if world == 1 and args.specialize and not args.no_generic and args.workload != "gauss":
             # the generic kernel (user values read at run time) on the same frame: must be
             # byte-identical; its rate is reported beside the specialised one
             g_flt = mm.Filter(src, tile_w=args.tile_w, specialize=False)
