@@ -180,6 +180,22 @@ class Invocation:
         else:
             raise MathMapError("cannot set user value `%s'" % name)
 
+    def set_curve(self, name, values):
+        """Sets a curve user value: 1024 floats, the sampled curve (userval.h:38,89-96)."""
+        u = self._index(name)
+        a = np.ascontiguousarray(values, dtype=np.float32)
+        if a.shape != (1024,):
+            raise MathMapError("a curve has 1024 samples")
+        self._check(lib().mmhip_set_curve(self._h, u["index"], a.ctypes.data_as(C.c_void_p)))
+
+    def set_gradient(self, name, rgba):
+        """Sets a gradient user value: 1024 packed 0xRRGGBBAA colours (userval.h:39,98-101)."""
+        u = self._index(name)
+        a = np.ascontiguousarray(rgba, dtype=np.uint32)
+        if a.shape != (1024,):
+            raise MathMapError("a gradient has 1024 samples")
+        self._check(lib().mmhip_set_gradient(self._h, u["index"], a.ctypes.data_as(C.c_void_p)))
+
     def set_image(self, name, array):
         """Binds a host uint8 array [H,W,3|4] as input drawable (uploaded once to HBM)."""
         u = self._index(name)

@@ -379,7 +379,19 @@ void hip_calc_lines(mmabi_slice_t *slice, mmabi_image_t *closure, int first_row,
                 }
                 break;
             }
-            default: break;   // curves / gradients: LUT upload is not wired up yet
+            case UvKind::Curve:      // curve_t.values: USER_CURVE_POINTS floats (userval.h:38,89-96)
+                if (a.v.curve && a.v.curve->values && mmhip_set_curve(hi, u.index, a.v.curve->values) != 0) {
+                    host_error(std::string("HIP backend: ") + mmhip_last_error());
+                    return;
+                }
+                break;
+            case UvKind::Gradient:   // gradient_t.values: USER_GRADIENT_POINTS color_t (userval.h:39,98-101)
+                if (a.v.gradient && a.v.gradient->values && mmhip_set_gradient(hi, u.index, a.v.gradient->values) != 0) {
+                    host_error(std::string("HIP backend: ") + mmhip_last_error());
+                    return;
+                }
+                break;
+            default: break;
         }
     }
     // new_template.c.in:238-239

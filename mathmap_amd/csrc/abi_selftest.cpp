@@ -359,6 +359,10 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
         drawable.scale_x = (float)((iw - 1) / 2.0);
         drawable.scale_y = (float)((ih - 1) / 2.0);
         drawable.middle_x = drawable.middle_y = 1.0f;
+        std::deque<std::vector<float>> curve_tabs;
+        std::deque<std::vector<mmabi_color_t>> grad_tabs;
+        std::deque<mmabi_curve_t> curves;
+        std::deque<mmabi_gradient_t> grads;
         for (const UservalInfo &u : m.main->uservals) {
             mmabi_userval_t &a = closure->v.closure.args[u.index];
             switch (u.kind) {
@@ -367,6 +371,23 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
                 case UvKind::Bool: a.v.bool_const = u.bdef; break;
                 case UvKind::Color: a.v.color.value = 0x000000ffu; break;
                 case UvKind::Image: a.v.image = image ? &drawable.image : nullptr; break;
+                // the deterministic tables of mathmap_amd/workloads.py test_curve / test_gradient
+                case UvKind::Curve:
+                    curve_tabs.emplace_back(1024);
+                    for (int i = 0; i < 1024; ++i) curve_tabs.back()[i] = ((float)i * (float)i) / (float)(1023.0 * 1023.0);
+                    curves.emplace_back();
+                    memset(&curves.back(), 0, sizeof(mmabi_curve_t));
+                    curves.back().values = curve_tabs.back().data();
+                    a.v.curve = &curves.back();
+                    break;
+                case UvKind::Gradient:
+                    grad_tabs.emplace_back(1024);
+                    for (unsigned i = 0; i < 1024; ++i)
+                        grad_tabs.back()[i] = ((i >> 2) << 24) | (((1023 - i) >> 2) << 16) | (0x40u << 8) | 0xFFu;
+                    grads.emplace_back();
+                    grads.back().values = grad_tabs.back().data();
+                    a.v.gradient = &grads.back();
+                    break;
                 default: break;
             }
         }

@@ -435,14 +435,18 @@ int mmhip_set_image_host(mmhip_invocation *inv, int index, const uint8_t *pixels
 
 int mmhip_set_curve(mmhip_invocation *inv, int index, const float *values1024) {
     if (!uv_info(inv, index, UvKind::Curve)) return -1;
-    memcpy(&inv->curves[(size_t)inv->uv[index].i * 1024], values1024, 1024 * sizeof(float));
+    float *dst = &inv->curves[(size_t)inv->uv[index].i * 1024];
+    if (memcmp(dst, values1024, 1024 * sizeof(float)) == 0) return 0;     // unchanged: no re-upload
+    memcpy(dst, values1024, 1024 * sizeof(float));
     inv->tables_dirty = true;
     return 0;
 }
 
 int mmhip_set_gradient(mmhip_invocation *inv, int index, const uint32_t *rgba1024) {
     if (!uv_info(inv, index, UvKind::Gradient)) return -1;
-    memcpy(&inv->gradients[(size_t)inv->uv[index].i * 1024], rgba1024, 1024 * sizeof(uint32_t));
+    uint32_t *dst = &inv->gradients[(size_t)inv->uv[index].i * 1024];
+    if (memcmp(dst, rgba1024, 1024 * sizeof(uint32_t)) == 0) return 0;
+    memcpy(dst, rgba1024, 1024 * sizeof(uint32_t));
     inv->tables_dirty = true;
     return 0;
 }

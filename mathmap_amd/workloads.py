@@ -370,6 +370,29 @@ filter tree (image in, int depth: 1-16 (4), float s: 0-1 (0.6))
 end
 """
 
+# curve and gradient user values (the shape of examples/Colors/Colorify.mm)
+CURVE_GRADIENT = """
+filter cg (image in, curve tone, gradient colors)
+  p = in(xy);
+  c = colors(tone(gray(p)));
+  rgba:[c[0], c[1], c[2], c[3] * p[3]]
+end
+"""
+
+
+def test_curve():
+    """Deterministic non-default curve (squares) shared by tests and the ABI self-test."""
+    import numpy as np
+    i = np.arange(1024, dtype=np.float32)
+    return (i * i) / np.float32(1023.0 * 1023.0)
+
+
+def test_gradient():
+    import numpy as np
+    i = np.arange(1024, dtype=np.uint32)
+    return ((i >> 2) << 24) | (((1023 - i) >> 2) << 16) | np.uint32(0x40 << 8) | np.uint32(0xFF)
+
+
 ALL = {
     "ident": IDENT,
     "mandelbrot": MANDELBROT,
@@ -384,6 +407,7 @@ ALL = {
     "visualize_fft": VISUALIZE_FFT,
     "convolve": CONVOLVE,
     "half_convolve": HALF_CONVOLVE,
+    "curve_gradient": CURVE_GRADIENT,
 }
 
 

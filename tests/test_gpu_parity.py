@@ -125,7 +125,7 @@ def test_mandelbrot_8192_stripe_property():
 
 
 @pytest.mark.parametrize("name,bands", [("mandelbrot", 1), ("pond", 3), ("droste", 2), ("gaussian_blur", 1),
-                                        ("closure_arg", 2)])
+                                        ("closure_arg", 2), ("curve_gradient", 2)])
 def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     """gen_and_load_hip_code + the returned mathfuncs, driven with reference-layout
     structures (include/mathmap_abi.h) the way mathmap_common.c drives the cc backend,
@@ -139,6 +139,9 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     inv = flt.invoke(w, h)
     if needs:
         inv.set_image("in", marlene)
+    if name == "curve_gradient":     # the self-test passes the same tables through curve_t / gradient_t
+        inv.set_curve("tone", W.test_curve())
+        inv.set_gradient("colors", W.test_gradient())
     want = inv.render(t=0.25)   # gaussian_blur: default dev = 0 -> sigma 0 -> FIR path with both passes skipped
     got = np.zeros((h, w, 4), np.uint8)
     img = np.ascontiguousarray(marlene)
@@ -344,6 +347,24 @@ def test_specialised_mandelbrot_8192_equals_generic():
     a = mm.Filter(W.MANDELBROT).invoke(w, h).render()
     b = mm.Filter(W.MANDELBROT, specialize=True).invoke(w, h).render()
     assert np.array_equal(a, b)
+
+
+def test_curve_and_gradient_user_values(marlene):
+    """Curve / gradient LUT user values (APPLY_CURVE / APPLY_GRADIENT, opmacros.h:192-194): default
+    ramps and explicitly set tables, HIP vs oracle, bit-exact."""
+    w = h = 128
+    img = np.ascontiguousarray(marlene[:h, :w])
+    flt = mm.Filter(W.CURVE_GRADIENT)
+    for tables in ({}, {"tone": W.test_curve(), "colors": W.test_gradient()}):
+        inv = flt.invoke(w, h)
+        inv.set_image("in", img)
+        if tables:
+            inv.set_curve("tone", tables["tone"])
+            inv.set_gradient("colors", tables["colors"])
+        got = inv.render()
+        want = CpuFilter(flt.ir_json).render(w, h, uservals=tables, images={"in": img})
+        assert np.array_equal(got, want), stats(got, want)
+    assert not np.array_equal(got, mm.Filter(W.IDENT).invoke(w, h).render())
 
 
 def _fft_case(src, w, h, uv, images):
