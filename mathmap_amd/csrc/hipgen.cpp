@@ -198,6 +198,12 @@ struct Generator {
                 if (opt.fast_math_exact && !strcmp(cn, "sqrt") && lhs && lhs->type == Ty::Float &&
                     r.args[0].type() == Ty::Float)
                     name = "mm_sqrt_f32";
+                // (float)sin((double)f), (float)cos((double)f): table-driven evaluation verified
+                // against glibc for every float below 2^22 (mm_fastmath.h, tools/verify_fastmath.c)
+                if (opt.fast_math_exact && lhs && lhs->type == Ty::Float && r.args.size() == 1 && r.args[0].type() == Ty::Float) {
+                    if (!strcmp(cn, "sin")) name = "mmf_sin_f32";
+                    else if (!strcmp(cn, "cos")) name = "mmf_cos_f32";
+                }
                 std::string s = name + "(";
                 for (size_t i = 0; i < r.args.size(); ++i) s += (i ? "," : "") + prim(r.args[i], sl);
                 return s + ")";
@@ -458,6 +464,13 @@ struct Generator {
         out << "#define MM_TILE_W " << ks.tile_w << "\n#define MM_TILE_H " << ks.tile_h << "\n";
         ks.unroll = opt.unroll > 0 ? opt.unroll : auto_unroll();
         out << "#define MM_UNROLL " << ks.unroll << "\n";
+        // float-argument sin/cos (mm_fastmath.h), the same text the host verifier compiles; it
+        // precedes the device prelude, whose complex functions use mmf_sincos_d
+        out << "#define MMF_FN static __device__ __forceinline__\n#define MMF_CONST_TABLE static __device__ const\n"
+               "#define MMF_FMA(a, b, c) __builtin_fma((a), (b), (c))\n#define MMF_RINT(a) __builtin_rint((a))\n"
+               "#define MMF_FABSF(a) __builtin_fabsf((a))\n#define MMF_FABS(a) __builtin_fabs((a))\n"
+               "#define MMF_SIN_SLOW(a) sin((a))\n#define MMF_COS_SLOW(a) cos((a))\n"
+            << device_fastmath_prelude() << "\n";
         out << device_prelude() << "\n";
         if (uses_noise(code.body)) {
             if (!noise_table_text())

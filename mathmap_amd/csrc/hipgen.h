@@ -42,6 +42,7 @@ struct KernelSource {
 KernelSource generate_hip(FilterCode &code, const KernelOptions &opt);
 const char *device_prelude();
 const char *device_noise_prelude();   // mm_noise_device.h
+const char *device_fastmath_prelude();   // mm_fastmath.h + tables
 const char *noise_table_text();        // nullptr when the libnoise table was not available at build time
 
 }  // namespace mm

@@ -165,7 +165,7 @@ MM_DEV mm_dc mm_dcdiv(mm_dc a, mm_dc b) {
 MM_DEV mm_dc mm_dclog(mm_dc z) { return mm_dcmake(log(hypot(z.re, z.im)), atan2(z.im, z.re)); }
 MM_DEV mm_dc mm_dcexp(mm_dc z) {
     double e = exp(z.re), s, c;
-    sincos(z.im, &s, &c);
+    mmf_sincos_d(z.im, &s, &c);
     if (z.im == 0.0) return mm_dcmake(e, z.im);
     return mm_dcmake(e * c, e * s);
 }
@@ -192,17 +192,17 @@ MM_DEV mm_complex cpowf(mm_complex x, mm_complex c) {
 }
 MM_DEV mm_complex csinf(mm_complex z) {
     double s, c;
-    sincos((double)z.re, &s, &c);
+    mmf_sincos_d((double)z.re, &s, &c);
     return mm_cmake((float)(s * cosh((double)z.im)), (float)(c * sinh((double)z.im)));
 }
 MM_DEV mm_complex ccosf(mm_complex z) {
     double s, c;
-    sincos((double)z.re, &s, &c);
+    mmf_sincos_d((double)z.re, &s, &c);
     return mm_cmake((float)(c * cosh((double)z.im)), (float)(-s * sinh((double)z.im)));
 }
 MM_DEV mm_complex ctanf(mm_complex z) {
     double s2, c2;
-    sincos(2.0 * (double)z.re, &s2, &c2);
+    mmf_sincos_d(2.0 * (double)z.re, &s2, &c2);
     double y2 = 2.0 * (double)z.im;
     if (fabs(y2) > 700.0) return mm_cmake((float)(4.0 * s2 * exp(-2.0 * fabs(y2)) ), (float)copysign(1.0, y2));
     double d = c2 + cosh(y2);
@@ -210,17 +210,17 @@ MM_DEV mm_complex ctanf(mm_complex z) {
 }
 MM_DEV mm_complex csinhf(mm_complex z) {
     double s, c;
-    sincos((double)z.im, &s, &c);
+    mmf_sincos_d((double)z.im, &s, &c);
     return mm_cmake((float)(sinh((double)z.re) * c), (float)(cosh((double)z.re) * s));
 }
 MM_DEV mm_complex ccoshf(mm_complex z) {
     double s, c;
-    sincos((double)z.im, &s, &c);
+    mmf_sincos_d((double)z.im, &s, &c);
     return mm_cmake((float)(cosh((double)z.re) * c), (float)(sinh((double)z.re) * s));
 }
 MM_DEV mm_complex ctanhf(mm_complex z) {
     double s2, c2;
-    sincos(2.0 * (double)z.im, &s2, &c2);
+    mmf_sincos_d(2.0 * (double)z.im, &s2, &c2);
     double x2 = 2.0 * (double)z.re;
     if (fabs(x2) > 700.0) return mm_cmake((float)copysign(1.0, x2), (float)(4.0 * s2 * exp(-2.0 * fabs(x2))));
     double d = cosh(x2) + c2;

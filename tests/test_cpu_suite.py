@@ -284,6 +284,22 @@ def test_byte_to_unit_newton_step_identity():
     assert (q != want).any()       # the plain f32 product alone is NOT enough
 
 
+def test_fastmath_sin_cos_equal_glibc_sampled():
+    """mm_fastmath.h (the text the JIT prelude embeds) against glibc's (float)sin((double)x) /
+    (float)cos((double)x): every 97th float below 2^22, both signs -- 26 M arguments.  The
+    exhaustive run (stride 1, 2.5e9 arguments, 0 mismatches) is recorded in
+    profiles/r01_verify_fastmath.json; tools/verify_fastmath.c is the checker."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_build", "verify_fastmath")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-pthread", os.path.join(ROOT, "tools", "verify_fastmath.c"),
+                    "-o", exe, "-lm"], check=True)
+    r = subprocess.run([exe, "97"], stdout=subprocess.PIPE, text=True)
+    rep = json.loads(r.stdout)
+    assert r.returncode == 0 and rep["sin_mismatches"] == 0 and rep["cos_mismatches"] == 0, rep
+    assert rep["checked"] > 25_000_000
+
+
 def test_sqrt_less_power_of_two_identity():
     """sqrt_rn(a) < K  <=>  0 <= a < K*K for K a power of two, checked on every float in a
     window of +-2^16 ulps around K*K and on random floats."""

@@ -161,7 +161,9 @@ end
 
 PROBES = [
     ("sqrt(abs(u))", "hypot-free sqrt", 0),
-    ("sin(u*7)", "sin", 1), ("cos(v*7)", "cos", 1), ("tan(u)", "tan", 1), ("atan(u*9, v*9)", "atan2", 1),
+    # sin / cos of a float: mm_fastmath.h, verified equal to glibc for every float below 2^22
+    ("sin(u*7)", "sin", 0), ("cos(v*7)", "cos", 0), ("sin(u*3000000+v)", "sin wide", 0), ("cos(v*4000000+u)", "cos wide", 0),
+    ("sin(u*1000000000)", "sin beyond 2^22 (OCML)", 1), ("tan(u)", "tan", 1), ("atan(u*9, v*9)", "atan2", 1),
     ("exp(u*3)", "exp", 1), ("log(abs(u)+0.001)", "log", 1), ("abs(ri:[u,v])", "hypot", 1),
     ("asin(u)", "asin", 1), ("acos(v)", "acos", 1), ("(abs(u)+0.01)^(v*3)", "pow", 2),
     ("sinh(u*2)", "sinh", 1), ("cosh(v*2)", "cosh", 1), ("tanh(u*2)", "tanh", 1), ("u % 0.37", "fmod", 0),
@@ -192,7 +194,7 @@ def test_real_math_float_ulps(expr, label, max_ulp):
     assert np.array_equal(np.isnan(a), np.isnan(b))
     ulps = np.abs(a[finite].view(np.int32).astype(np.int64) - b[finite].view(np.int32).astype(np.int64))
     assert ulps.max() <= max_ulp, "%s: max %d ulps" % (label, ulps.max())
-    assert (ulps == 0).mean() > 0.999, "%s: only %.5f identical" % (label, (ulps == 0).mean())
+    assert (ulps == 0).mean() > (0.98 if "beyond" in label else 0.999), "%s: only %.5f identical" % (label, (ulps == 0).mean())
 
 
 COMPLEX_PROBES = ["exp(z)", "log(z)", "sqrt(z)", "sin(z)", "cos(z)", "tan(z)", "z^ri:[1.3,0.4]", "sinh(z)", "cosh(z)",
