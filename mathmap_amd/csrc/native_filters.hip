@@ -145,38 +145,76 @@ __device__ __forceinline__ double iir_edge_step(int j, double s0, double s1, dou
     return acc;
 }
 
-__global__ void __launch_bounds__(256) k_iir_causal(const float *__restrict__ in, double *__restrict__ scratch,
-                                                    LineArgs g, IirCoef c) {
-    const long L = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)g.lines * 4;
-    if (L >= stride) return;
-    const float *p = in + L;
-    double *sc = scratch + L;
-    const int n = g.n;
-    const float initial = p[0];
+// Element source of a scan.  fetch() is the bare load (its result is not touched until the
+// element is consumed, so a block's 16 prefetches stay in flight while the previous block is
+// computed); decode() turns the loaded word into the float the recurrence sees.
+// A float map laid out in[k][line][ch] ...
+struct MapSrc {
+    typedef float raw_t;
+    const float *p;        // already offset to this lane's (line, channel)
+    long stride;           // lines * 4
+    __device__ __forceinline__ raw_t fetch(int k) const { return p[(long)k * stride]; }
+    __device__ __forceinline__ float decode(raw_t v) const { return v; }
+    __device__ __forceinline__ MapSrc for_lane(long L) const { return MapSrc{p + L, stride}; }
+};
+// ... or the input drawable itself when render_image's coordinate mapping (builtins.c:303-343)
+// is the identity -- a drawable of the render size, which the host establishes by evaluating
+// the mapping for every row and column (same float operations) before it picks this source.
+// render_image is then fused into the first pass: 4 instead of 16 B/px read, no 4.3 GB map.
+struct DrawableSrc {
+    typedef uint32_t raw_t;
+    const uint32_t *p;     // offset to this lane's column
+    int sw;                // source pitch in pixels
+    int shift;             // 24 - 8*channel
+    __device__ __forceinline__ raw_t fetch(int k) const { return p[(long)k * sw]; }
+    // TUPLE_FROM_COLOR: (c >> shift & 0xff) / 255.0 == ... * (1.0 / 255.0) for all 256 bytes (enumerated)
+    __device__ __forceinline__ float decode(raw_t c) const { return (float)((double)((c >> shift) & 0xff) * (1.0 / 255.0)); }
+    __device__ __forceinline__ DrawableSrc for_lane(long L) const { return DrawableSrc{p + (L >> 2), sw, 24 - 8 * (int)(L & 3)}; }
+};
+
+// Causal sweep.  Nothing but the recurrence state at every IIR_U-th step leaves the kernel:
+// ckpt[b][i][lane] = v(kb-1-i), i = 0..3, kb = b*IIR_U, b >= 1 -- 2 bytes per element instead of
+// the 8 a full f64 partial-sum map would take.  The anticausal kernel re-runs the causal
+// recurrence block by block from these checkpoints (same operations, same order: identical
+// values) right before it needs them.
+template <class Src>
+__device__ __forceinline__ void causal_sweep(const Src &src, double *__restrict__ ck, long stride, int n, const IirCoef &c) {
+    const float initial = src.decode(src.fetch(0));
     double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-    int k = 0;
-    for (; k < 4 && k < n; ++k) {
-        const double s0 = (double)p[(long)k * stride];
-        const double acc = iir_edge_step(k, s0, s1, s2, s3, v1, v2, v3, c.n_p, c.d_p, c.bd_p, initial);
-        sc[(long)k * stride] = acc;
-        s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-        v4 = v3; v3 = v2; v2 = v1; v1 = acc;
-    }
-    float cur[IIR_U], nxt[IIR_U];
+    typename Src::raw_t cur[IIR_U], nxt[IIR_U];
 #pragma unroll
-    for (int u = 0; u < IIR_U; ++u) cur[u] = (k + u < n) ? p[(long)(k + u) * stride] : 0.0f;
-    for (; k < n; k += IIR_U) {
+    for (int u = 0; u < IIR_U; ++u) cur[u] = src.fetch(u < n ? u : 0);
+    for (int kb = 0; kb < n; kb += IIR_U) {
 #pragma unroll
-        for (int u = 0; u < IIR_U; ++u) nxt[u] = (k + IIR_U + u < n) ? p[(long)(k + IIR_U + u) * stride] : 0.0f;
+        for (int u = 0; u < IIR_U; ++u) nxt[u] = src.fetch(kb + IIR_U + u < n ? kb + IIR_U + u : 0);   // past the end: unused
+        if (kb > 0) {
+            double *q = ck + (long)(kb / IIR_U) * 4 * stride;
+            q[0] = v1;
+            q[stride] = v2;
+            q[2 * stride] = v3;
+            q[3 * stride] = v4;
+        }
+        if (kb > 0 && kb + IIR_U <= n) {
+            // interior block: no edge steps, no bounds -- straight-line code, the state "shifts"
+            // are register renames
 #pragma unroll
-        for (int u = 0; u < IIR_U; ++u) {
-            if (k + u < n) {
-                const double s0 = (double)cur[u];
+            for (int u = 0; u < IIR_U; ++u) {
+                const double s0 = (double)src.decode(cur[u]);
                 const double acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
-                sc[(long)(k + u) * stride] = acc;
                 s4 = s3; s3 = s2; s2 = s1; s1 = s0;
                 v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < IIR_U; ++u) {
+                const int k = kb + u;
+                if (k < n) {
+                    const double s0 = (double)src.decode(cur[u]);
+                    const double acc = (kb == 0 && u < 4) ? iir_edge_step(u, s0, s1, s2, s3, v1, v2, v3, c.n_p, c.d_p, c.bd_p, initial)
+                                                           : iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
+                    s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                    v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                }
             }
         }
 #pragma unroll
@@ -184,56 +222,112 @@ __global__ void __launch_bounds__(256) k_iir_causal(const float *__restrict__ in
     }
 }
 
-__global__ void __launch_bounds__(256) k_iir_anticausal_T(const float *__restrict__ in, const double *__restrict__ scratch,
-                                                          float *__restrict__ outT, LineArgs g, IirCoef c) {
-    // wave-private staging tile: 16 lines x IIR_U steps x 4 channels, line stride padded by 4 floats
-    __shared__ float tile[4][16 * (IIR_U * 4 + 4)];
-    const long L = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)g.lines * 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *tw = tile[wave];
-    const int ll = lane >> 2, ch = lane & 3;                // line within the wave's 16, channel
-    const long line0 = ((long)blockIdx.x * 256 + (long)wave * 64) >> 2;   // first line of this wave
-    const bool active = L < stride;
-    const float *p = in + (active ? L : 0);
-    const double *sc = scratch + (active ? L : 0);
-    const int n = g.n;
-    const float initial = p[(long)(n - 1) * stride];
-    double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-    // process blocks of IIR_U steps from the end; block b covers k in [kb, kb+IIR_U)
-    const int nblocks = (n + IIR_U - 1) / IIR_U;
-    float cur_s[IIR_U], nxt_s[IIR_U];
-    double cur_v[IIR_U], nxt_v[IIR_U];
-    {
-        const int kb = (nblocks - 1) * IIR_U;
+// One block of the causal recurrence re-run from its checkpoint (block 0: from the edge).
+template <bool GUARD, class Src>
+__device__ __forceinline__ void rerun_block(const Src &src, int b, int n, const typename Src::raw_t *in, const typename Src::raw_t *r4,
+                                            const double *ckv, const IirCoef &c, float initial_p, double *vc) {
+    const int kb = b * IIR_U;
+    double cs1 = src.decode(r4[3]), cs2 = src.decode(r4[2]), cs3 = src.decode(r4[1]), cs4 = src.decode(r4[0]);
+    double cv1 = ckv[0], cv2 = ckv[1], cv3 = ckv[2], cv4 = ckv[3];
 #pragma unroll
-        for (int u = 0; u < IIR_U; ++u) {
-            const int k = kb + u;
-            cur_s[u] = (k < n) ? p[(long)k * stride] : 0.0f;
-            cur_v[u] = (k < n) ? sc[(long)k * stride] : 0.0;
+    for (int u = 0; u < IIR_U; ++u) {
+        if (!GUARD) {
+            const double s0 = (double)src.decode(in[u]);
+            const double acc = iir_step(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
+            vc[u] = acc;
+            cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
+            cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
+        } else {
+            vc[u] = 0.0;
+            if (kb + u < n) {
+                const double s0 = (double)src.decode(in[u]);
+                const double acc = (b == 0 && u < 4) ? iir_edge_step(u, s0, cs1, cs2, cs3, cv1, cv2, cv3, c.n_p, c.d_p, c.bd_p, initial_p)
+                                                     : iir_step(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
+                vc[u] = acc;
+                cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
+                cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
+            }
         }
+    }
+}
+
+// Anticausal sweep + causal re-run + sum, written transposed (see the layout note above).
+// Software-pipelined three deep: while block b takes its anticausal steps, block b-1's causal
+// values are re-run -- two independent dependency chains interleaved step by step, which is
+// what fills the f64 pipeline of a SIMD that holds a single wave -- and block b-2 is in flight
+// from memory.
+template <class Src>
+__device__ __forceinline__ void anticausal_sweep(const Src &src, const double *__restrict__ ck, long stride, int n,
+                                                 const IirCoef &c, float *tw, int lane, long line0, int lines,
+                                                 float *__restrict__ outT, bool active) {
+    typedef typename Src::raw_t raw_t;
+    const int ll = lane >> 2, ch = lane & 3;                // line within the wave's 16, channel
+    const float initial_m = src.decode(src.fetch(n - 1)), initial_p = src.decode(src.fetch(0));
+    double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;      // anticausal state
+    const int nblocks = (n + IIR_U - 1) / IIR_U;
+    raw_t cur_s[IIR_U], nxt_s[IIR_U], nn_s[IIR_U], nxt4[4], nn4[4];
+    double nxt_ck[4], nn_ck[4], vc_cur[IIR_U], vc_nxt[IIR_U];
+    auto load_block = [&](int blk, raw_t *in, raw_t *r4, double *ckv) {
+        const int kb = blk * IIR_U;
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) in[u] = src.fetch(kb + u < n ? kb + u : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r4[i] = src.fetch(blk > 0 ? kb - 4 + i : 0);
+            ckv[i] = blk > 0 ? ck[((long)blk * 4 + i) * stride] : 0.0;
+        }
+    };
+    auto interior_causal = [&](int blk) { return blk > 0 && (blk + 1) * IIR_U <= n; };
+    {   // prologue: the last block's inputs and causal values, the one before it on its way
+        raw_t r4[4];
+        double ckv[4];
+        load_block(nblocks - 1, cur_s, r4, ckv);
+        if (nblocks > 1) load_block(nblocks - 2, nxt_s, nxt4, nxt_ck);
+        rerun_block<true>(src, nblocks - 1, n, cur_s, r4, ckv, c, initial_p, vc_cur);
     }
     for (int b = nblocks - 1; b >= 0; --b) {
         const int kb = b * IIR_U;
-        if (b > 0) {
+        if (b > 1) load_block(b - 2, nn_s, nn4, nn_ck);
+        if (b > 0 && kb + 2 * IIR_U <= n && interior_causal(b - 1)) {
+            // both chains unguarded: causal step u of block b-1 next to anticausal step 15-u of block b
+            double cs1 = src.decode(nxt4[3]), cs2 = src.decode(nxt4[2]), cs3 = src.decode(nxt4[1]), cs4 = src.decode(nxt4[0]);
+            double cv1 = nxt_ck[0], cv2 = nxt_ck[1], cv3 = nxt_ck[2], cv4 = nxt_ck[3];
 #pragma unroll
             for (int u = 0; u < IIR_U; ++u) {
-                nxt_s[u] = p[(long)(kb - IIR_U + u) * stride];
-                nxt_v[u] = sc[(long)(kb - IIR_U + u) * stride];
+                {
+                    const double s0 = (double)src.decode(nxt_s[u]);
+                    const double acc = iir_step(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
+                    vc_nxt[u] = acc;
+                    cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
+                    cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
+                }
+                {
+                    const int ua = IIR_U - 1 - u;
+                    const double s0 = (double)src.decode(cur_s[ua]);
+                    const double acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
+                    tw[ll * (IIR_U * 4 + 4) + ua * 4 + ch] = (float)(vc_cur[ua] + acc);   // transfer_pixels, gauss.c:117-124
+                    s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                    v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                }
             }
-        }
+        } else {
+            if (b > 0) {
+                if (interior_causal(b - 1)) rerun_block<false>(src, b - 1, n, nxt_s, nxt4, nxt_ck, c, initial_p, vc_nxt);
+                else rerun_block<true>(src, b - 1, n, nxt_s, nxt4, nxt_ck, c, initial_p, vc_nxt);
+            }
 #pragma unroll
-        for (int u = IIR_U - 1; u >= 0; --u) {
-            const int k = kb + u;
-            if (k < n) {
-                const int j = n - 1 - k;                     // steps from the end
-                const double s0 = (double)cur_s[u];
-                double acc;
-                if (j < 4) acc = iir_edge_step(j, s0, s1, s2, s3, v1, v2, v3, c.n_m, c.d_m, c.bd_m, initial);
-                else acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
-                tw[ll * (IIR_U * 4 + 4) + u * 4 + ch] = (float)(cur_v[u] + acc);   // transfer_pixels, gauss.c:117-124
-                s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-                v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+            for (int u = IIR_U - 1; u >= 0; --u) {
+                const int k = kb + u;
+                if (k < n) {
+                    const int j = n - 1 - k;                     // steps from the end
+                    const double s0 = (double)src.decode(cur_s[u]);
+                    double acc;
+                    if (j < 4) acc = iir_edge_step(j, s0, s1, s2, s3, v1, v2, v3, c.n_m, c.d_m, c.bd_m, initial_m);
+                    else acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
+                    tw[ll * (IIR_U * 4 + 4) + u * 4 + ch] = (float)(vc_cur[u] + acc);   // transfer_pixels, gauss.c:117-124
+                    s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                    v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                }
             }
         }
         // the tile is private to this wave: a wave-level fence suffices
@@ -246,7 +340,7 @@ __global__ void __launch_bounds__(256) k_iir_anticausal_T(const float *__restric
             const int tl = i * 4 + (lane >> 4), kk = lane & 15;
             const long line = line0 + tl;
             const int k = kb + kk;
-            if (line < g.lines && k < n) {
+            if (line < lines && k < n) {
                 const float4 v = *(const float4 *)&tw[tl * (IIR_U * 4 + 4) + kk * 4];
                 *(float4 *)&outT[(line * (long)n + k) * 4] = v;
             }
@@ -255,8 +349,33 @@ __global__ void __launch_bounds__(256) k_iir_anticausal_T(const float *__restric
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int u = 0; u < IIR_U; ++u) { cur_s[u] = nxt_s[u]; cur_v[u] = nxt_v[u]; }
+        for (int u = 0; u < IIR_U; ++u) { cur_s[u] = nxt_s[u]; nxt_s[u] = nn_s[u]; vc_cur[u] = vc_nxt[u]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { nxt4[i] = nn4[i]; nxt_ck[i] = nn_ck[i]; }
     }
+    (void)active;
+}
+
+template <class Src>
+__global__ void __launch_bounds__(256) k_iir_causal(Src in, double *__restrict__ ckpt, LineArgs g, IirCoef c) {
+    const long L = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)g.lines * 4;
+    if (L >= stride) return;
+    causal_sweep(in.for_lane(L), ckpt + L, stride, g.n, c);
+}
+
+template <class Src>
+__global__ void __launch_bounds__(256) k_iir_anticausal_T(Src in, const double *__restrict__ ckpt, float *__restrict__ outT,
+                                                          LineArgs g, IirCoef c) {
+    // wave-private staging tile: 16 lines x IIR_U steps x 4 channels, line stride padded by 4 floats
+    __shared__ float tile[4][16 * (IIR_U * 4 + 4)];
+    const long L = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)g.lines * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long line0 = ((long)blockIdx.x * 256 + (long)wave * 64) >> 2;   // first line of this wave
+    const bool active = L < stride;
+    const long Lc = active ? L : 0;      // idle lanes of the last wave shadow lane 0; their tile rows are never written out
+    anticausal_sweep(in.for_lane(Lc), ckpt + Lc, stride, g.n, c, tile[wave], lane, line0, g.lines, outT, active);
 }
 
 // ---- K5: FIR path for sigma < 0.5 px on either axis (gauss.c:264-639) ----------------------------
@@ -400,16 +519,7 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         w = in.w;
         h = in.h;
         if (w != rw || h != rh) { *err = "gaussian_blur: float-map input of a different size is not supported"; return -1; }
-        if (hipMemcpyAsync(out_map, in.data, (size_t)w * h * 16, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-            *err = "gaussian_blur: copy failed";
-            return -1;
-        }
-    } else if (in.kind == IMG_DRAWABLE) {
-        long n = (long)w * h;
-        k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-            (const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y, in.middle_x, in.middle_y, img.resized, img.xf,
-            img.yf, 0u, 0u, 0, (float4 *)out_map, w, h);
-    } else {
+    } else if (in.kind != IMG_DRAWABLE) {
         *err = "gaussian_blur: input image is not bound";
         return -1;
     }
@@ -418,23 +528,75 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
     float ay = (float)((float)(h - 1) / 2.0);
     ay *= -1.0f;
     float hs = (float)fabs(hdev * ax), vs = (float)fabs(vdev * ay);
-    // workspace: f64 scan scratch (w*h*4 doubles) followed by the intermediate map
-    const size_t scratch_bytes = (size_t)w * h * 4 * sizeof(double);
+    // workspace: the scans' checkpoints (4 doubles per line*channel every IIR_U steps, the larger of
+    // the two passes; also covers the FIR path's flags and taps) followed by the intermediate map
+    const size_t ck_v = (size_t)((h + IIR_U - 1) / IIR_U) * 4 * ((size_t)w * 4) * sizeof(double);
+    const size_t ck_h = (size_t)((w + IIR_U - 1) / IIR_U) * 4 * ((size_t)h * 4) * sizeof(double);
+    const size_t scratch_bytes = ((std::max(ck_v, ck_h) + (size_t)std::max(w, h) * 64 + (size_t)(w + h) * sizeof(int) + 65536) + 255) & ~(size_t)255;
     const size_t map_bytes = (size_t)w * h * 4 * sizeof(float);
     char *wsp = (char *)ws.reserve(scratch_bytes + map_bytes);
     if (!wsp) { *err = "gaussian_blur: out of device memory for the scan workspace"; return -1; }
     double *scratch = (double *)wsp;
     float *mapT = (float *)(wsp + scratch_bytes);
-    if (hs < 0.5f || vs < 0.5f)     // gauss.c:662-665
+    // materialise the input map only where a kernel needs it whole (the FIR path)
+    auto render_input = [&]() -> int {
+        if (in.kind == IMG_FLOATMAP) {
+            if (hipMemcpyAsync(out_map, in.data, (size_t)w * h * 16, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                *err = "gaussian_blur: copy failed";
+                return -1;
+            }
+        } else {
+            const long n = (long)w * h;
+            k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+                (const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y, in.middle_x, in.middle_y, img.resized, img.xf,
+                img.yf, 0u, 0u, 0, (float4 *)out_map, w, h);
+        }
+        return 0;
+    };
+    if (hs < 0.5f || vs < 0.5f) {     // gauss.c:662-665
+        if (render_input() != 0) return -1;
         return gauss_rle(out_map, mapT, w, h, hs, vs, ws, wsp, s, err);
+    }
     IirCoef c;
-    // vertical pass first (gauss.c:155-201): lines = columns, n = h; result transposed into mapT[w][h][4]
+    // Does render_image map output pixel (x, y) to texel (x, y)?  Evaluated on the host with the
+    // operations of k_render_drawable (IEEE float: same results), once per row and column.
+    bool identity = in.kind == IMG_DRAWABLE && in.w == w && in.h == h;
+    if (identity) {
+        const float ax = (float)((float)(w - 1) / 2.0), bx = ax;
+        const float by = (float)((float)(h - 1) / 2.0);
+        const float ay2 = (float)(by * -1.0);
+        for (int i = 0; i < w && identity; ++i) {
+            float x = ((float)i - bx) / ax;
+            if (img.resized) x *= img.xf;
+            x = (x + in.middle_x) * in.scale_x;
+            x += 0.5;
+            identity = (int)floor((double)x) == i;
+        }
+        for (int i = 0; i < h && identity; ++i) {
+            float y = ((float)i - by) / ay2;
+            if (img.resized) y *= img.yf;
+            y = -((y - in.middle_y) * in.scale_y);
+            y += 0.5;
+            identity = (int)floor((double)y) == i;
+        }
+    }
+    if (in.kind == IMG_DRAWABLE && !identity && render_input() != 0) return -1;
+    // vertical pass first (gauss.c:155-201): lines = columns, n = h; result transposed into mapT[w][h][4].
+    // Its two sweeps read the input where it lies: the float map, or -- identity mapping -- the
+    // drawable itself: no intermediate map, 4 instead of 16 B/px.
     find_iir_constants(c, vs);
     {
         LineArgs g{h, w};
         const unsigned blocks = (unsigned)(((long)w * 4 + 255) / 256);
-        k_iir_causal<<<blocks, 256, 0, s>>>(out_map, scratch, g, c);
-        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(out_map, scratch, mapT, g, c);
+        if (in.kind == IMG_FLOATMAP || !identity) {
+            const MapSrc src{in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map, (long)w * 4};
+            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
+        } else {
+            const DrawableSrc src{(const uint32_t *)in.data, in.w, 0};
+            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
+        }
     }
     // horizontal pass (gauss.c:203-252): in mapT the original rows are the "columns"; transposing again
     // restores the original layout in out_map
@@ -442,8 +604,9 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
     {
         LineArgs g{w, h};
         const unsigned blocks = (unsigned)(((long)h * 4 + 255) / 256);
-        k_iir_causal<<<blocks, 256, 0, s>>>(mapT, scratch, g, c);
-        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(mapT, scratch, out_map, g, c);
+        const MapSrc src{mapT, (long)h * 4};
+        k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
+        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map, g, c);
     }
     if (hipGetLastError() != hipSuccess) { *err = "gaussian_blur: kernel launch failed"; return -1; }
     return 0;

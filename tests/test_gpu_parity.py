@@ -80,6 +80,34 @@ def test_hip_matches_oracle(name, uv, tol, size):
     assert mx <= tol or frac < 1e-4, "%s %s: max %d, %d differ, %d by >1" % (name, uv, mx, nd, n1)
 
 
+@pytest.mark.parametrize("size", [(37, 19), (64, 48), (129, 65), (5, 3), (16, 16), (17, 33), (300, 7)])
+def test_gauss_iir_float_map_is_bit_exact(size):
+    """The recursive Gaussian keeps the reference's operation order in f64 (gauss.c:126-262), so
+    the blurred float map -- read back through float-map output, no byte quantisation -- must
+    equal the oracle's bit for bit; sizes below, at and across the 16-step block boundaries of
+    the scan kernels."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = size
+    img = W.synthetic_image(w, h, seed=11)
+    uv = {"hdev": 4.0 / max(w - 1, 1), "vdev": 3.0 / max(h - 1, 1)}     # sigma = 2 px and 1.5 px: IIR path
+    flt = mm.Filter(W.GAUSS_DIRECT)
+    inv = flt.invoke(w, h)
+    for k, v in uv.items():
+        inv.set(k, v)
+    inv.set_image("in", img)
+    dev = lib().mmhip_device_alloc(w * h * 16)
+    try:
+        inv.render_rows(dev, 0, h, floatmap=True)
+        inv.sync()
+        got = np.empty((h, w, 4), np.float32)
+        assert lib().mmhip_copy_to_host(got.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * 16) == 0
+    finally:
+        lib().mmhip_device_free(C.c_void_p(dev))
+    want = CpuFilter(flt.ir_json).render(w, h, uservals=uv, images={"in": img}, floatmap=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+
+
 def test_nearest_sampling_matches_oracle():
     w, h = 300, 200
     img = W.synthetic_image(w, h, seed=5)
