@@ -91,6 +91,9 @@ int mmhip_set_bool(mmhip_invocation *inv, int index, int value);
 int mmhip_set_color(mmhip_invocation *inv, int index, float r, float g, float b, float a);
 /* curve = 1024 samples of the transfer curve over [0,1]; gradient = 1024 packed 0xRRGGBBAA colours
    (USER_CURVE_POINTS / USER_GRADIENT_POINTS, userval.h:36-37).  Defaults: identity ramp, grey ramp. */
+/* Row-striped frames with native-filter calls: allow native filters to fill only the rows a
+   stripe render reads (+- margin rows, plus the filter's own halo).  -1 = whole map (default). */
+int mmhip_set_native_row_margin(mmhip_invocation *inv, int margin);
 int mmhip_set_curve(mmhip_invocation *inv, int index, const float *values1024);
 int mmhip_set_gradient(mmhip_invocation *inv, int index, const uint32_t *rgba1024);
 int mmhip_set_by_name(mmhip_invocation *inv, const char *name, const char *value);  /* -Dname=value */

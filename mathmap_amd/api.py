@@ -210,6 +210,11 @@ class Invocation:
             self._keep.append(keepalive)
         self._check(lib().mmhip_set_image_device(self._h, u["index"], C.c_void_p(device_ptr), width, height))
 
+    def set_native_row_margin(self, margin):
+        """Striped frames: let native filters (gaussian_blur) fill only the rows a stripe render
+        reads, +- `margin` rows, plus their own halo.  -1 restores whole maps."""
+        self._check(lib().mmhip_set_native_row_margin(self._h, margin))
+
     def set_edge_colors(self, cx, cy):
         self._check(lib().mmhip_set_edge_colors(self._h, cx, cy))
 

@@ -25,9 +25,13 @@ struct NativeWorkspace {
 
 // Runs native filter `func` with the arguments recorded by the prologue kernel.
 // `out_map` is a float[h][w][4] device buffer.  Returns 0 on success.
+// `row_lo, row_hi`: the rows of the map the caller is going to read.  Filters whose output
+// rows depend on a bounded neighbourhood of input rows (gaussian_blur: a halo of ceil(22.7 sigma)
+// rows, below which the recurrences' start-up error is under 1e-17 of the value) may fill only
+// those rows plus their halo; [0, render_h) asks for the whole map.
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
-                      std::string *err);
+                      std::string *err, int row_lo, int row_hi);
 
 // native_fft.hip: convolve / half_convolve / visualize_fft (native-filters/convolve.c)
 int fft_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images, int render_w,

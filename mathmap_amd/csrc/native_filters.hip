@@ -509,7 +509,7 @@ int gauss_rle(float *map, float *tmp, int w, int h, float hs, float vs, NativeWo
 }
 
 int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, int rw, int rh, float *out_map,
-                  NativeWorkspace &ws, hipStream_t s, std::string *err) {
+                  NativeWorkspace &ws, hipStream_t s, std::string *err, int row_lo, int row_hi) {
     const HImage &img = rec.args[0].img;
     float hdev = rec.args[1].f, vdev = rec.args[2].f;
     if (img.idx < 0 || img.idx >= (int)images.size()) { *err = "gaussian_blur: input is not a bitmap image"; return -1; }
@@ -581,32 +581,46 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         }
     }
     if (in.kind == IMG_DRAWABLE && !identity && render_input() != 0) return -1;
-    // vertical pass first (gauss.c:155-201): lines = columns, n = h; result transposed into mapT[w][h][4].
-    // Its two sweeps read the input where it lies: the float map, or -- identity mapping -- the
-    // drawable itself: no intermediate map, 4 instead of 16 B/px.
+    // Row window: a caller that only reads rows [row_lo, row_hi) (one GPU's stripe of a striped
+    // frame; inputs are replicated on every GPU, so the halo is computed locally, not exchanged)
+    // gets those rows plus a halo of ceil(22.7 sigma_v) rows -- the recurrences' poles are
+    // exp(-1.783/sigma) and exp(-1.723/sigma) (gauss.c:57-58), so the different start-up at the
+    // window edge has decayed below 1e-17 of the value, under half an ulp of the f64 sums, by the
+    // time the sweep reaches a row that is read.  True image edges keep the reference's start-up.
+    int y0 = 0, y1 = h;
+    if (row_lo > 0 || row_hi < h) {
+        const int halo = (int)ceil(22.7 * (double)vs) + 2;
+        y0 = std::max(0, row_lo - halo);
+        y1 = std::min(h, row_hi + halo);
+        if (y1 <= y0) return 0;
+    }
+    const int hn = y1 - y0;
+    // vertical pass first (gauss.c:155-201): lines = columns, n = rows of the window; result transposed
+    // into mapT[w][hn][4].  Its two sweeps read the input where it lies: the float map, or --
+    // identity mapping -- the drawable itself: no intermediate map, 4 instead of 16 B/px.
     find_iir_constants(c, vs);
     {
-        LineArgs g{h, w};
+        LineArgs g{hn, w};
         const unsigned blocks = (unsigned)(((long)w * 4 + 255) / 256);
         if (in.kind == IMG_FLOATMAP || !identity) {
-            const MapSrc src{in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map, (long)w * 4};
+            const MapSrc src{(in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map) + (long)y0 * w * 4, (long)w * 4};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
             k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
         } else {
-            const DrawableSrc src{(const uint32_t *)in.data, in.w, 0};
+            const DrawableSrc src{(const uint32_t *)in.data + (long)y0 * in.w, in.w, 0};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
             k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
         }
     }
-    // horizontal pass (gauss.c:203-252): in mapT the original rows are the "columns"; transposing again
-    // restores the original layout in out_map
+    // horizontal pass (gauss.c:203-252): in mapT the window's rows are the "columns"; transposing again
+    // restores the original layout, written to rows [y0, y1) of out_map
     find_iir_constants(c, hs);
     {
-        LineArgs g{w, h};
-        const unsigned blocks = (unsigned)(((long)h * 4 + 255) / 256);
-        const MapSrc src{mapT, (long)h * 4};
+        LineArgs g{w, hn};
+        const unsigned blocks = (unsigned)(((long)hn * 4 + 255) / 256);
+        const MapSrc src{mapT, (long)hn * 4};
         k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map, g, c);
+        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c);
     }
     if (hipGetLastError() != hipSuccess) { *err = "gaussian_blur: kernel launch failed"; return -1; }
     return 0;
@@ -661,8 +675,9 @@ void launch_supersample_combine(const unsigned char *longs, const unsigned char 
 
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
-                      std::string *err) {
-    if (func == "native_filter_gaussian_blur") return gaussian_blur(rec, images, render_w, render_h, out_map, ws, stream, err);
+                      std::string *err, int row_lo, int row_hi) {
+    if (func == "native_filter_gaussian_blur")
+        return gaussian_blur(rec, images, render_w, render_h, out_map, ws, stream, err, row_lo, row_hi);
     if (func == "RENDER") {   // render_image (builtins.c:267-346), drawable / float-map branches
         const HImage &img = rec.args[0].img;
         if (img.idx < 0 || img.idx >= (int)images.size()) { *err = "render(): rendering a filter closure is not supported by the HIP backend yet"; return -1; }

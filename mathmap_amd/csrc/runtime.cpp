@@ -302,6 +302,7 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
     inv->native_maps.assign(f->ks.natives.size(), nullptr);
     inv->native_memo.resize(f->ks.natives.size());
     inv->native_memo_gen.assign(f->ks.natives.size(), 0);
+    inv->native_rows.assign(f->ks.natives.size(), {0, 0});
     if (inv->images.empty()) { HImageDesc d{}; d.kind = IMG_NULL; inv->images.push_back(d); }
     auto bail = [&](const char *what, hipError_t e) -> mmhip_invocation * {
         fail(std::string(what) + ": " + hipGetErrorString(e));
@@ -451,6 +452,16 @@ int mmhip_set_gradient(mmhip_invocation *inv, int index, const uint32_t *rgba102
     return 0;
 }
 
+// Row-striped rendering of filters with native-filter calls (one stripe per GPU): with a margin
+// >= 0 a render of rows [a, b) of the full frame lets the native filters fill only rows
+// [a - margin, b + margin) of their maps (plus whatever halo the filter itself needs).  The caller
+// asserts that the filter samples a native map no further than `margin` rows from the output row
+// (0 for `blurred(xy)`).  -1 (default): always the whole map, like the reference.
+int mmhip_set_native_row_margin(mmhip_invocation *inv, int margin) {
+    inv->native_row_margin = margin;
+    return 0;
+}
+
 int mmhip_set_edge_colors(mmhip_invocation *inv, uint32_t cx, uint32_t cy) {
     inv->edge_color_x = cx;
     inv->edge_color_y = cy;
@@ -510,14 +521,23 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
         if (!rec.executed) continue;
         int slot = inv->native_slot_base + (int)k;
         // memo (native-filters/cache.c:110-147): same arguments on unchanged inputs -> keep the map
+        // rows of the map this launch may read: everything, or -- opt-in, full-frame regions only --
+        // the stripe being rendered (the filter samples the map within its own rows +- margin)
+        int want_lo = 0, want_hi = a.render_height;
+        if (inv->native_row_margin >= 0 && a.region_x == 0 && a.region_y == 0 && a.region_width == a.render_width &&
+            a.region_height == a.render_height) {
+            want_lo = std::max(0, a.first_row - inv->native_row_margin);
+            want_hi = std::min(a.render_height, a.first_row + a.num_rows + inv->native_row_margin);
+        }
         if (inv->native_maps[k] && inv->native_memo_gen[k] == inv->input_generation &&
-            memcmp(&inv->native_memo[k], &rec, sizeof rec) == 0)
+            memcmp(&inv->native_memo[k], &rec, sizeof rec) == 0 && inv->native_rows[k].first <= want_lo &&
+            inv->native_rows[k].second >= want_hi)
             continue;
         size_t bytes = (size_t)a.render_width * a.render_height * 16;
         if (!inv->native_maps[k]) HIP_TRY(hipMalloc(&inv->native_maps[k], bytes));
         std::string err;
         int rc = run_native_filter(f->ks.natives[k].func, rec, inv->images, a.render_width, a.render_height,
-                                   (float *)inv->native_maps[k], inv->ws, s, &err);
+                                   (float *)inv->native_maps[k], inv->ws, s, &err, want_lo, want_hi);
         if (rc != 0) return fail(err);
         HImageDesc &d = inv->images[slot];
         d.data = inv->native_maps[k];
@@ -530,6 +550,7 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
         d.ay *= -1.0f;
         inv->native_memo[k] = rec;
         inv->native_memo_gen[k] = inv->input_generation;
+        inv->native_rows[k] = {want_lo, want_hi};
         table_changed = true;
     }
     if (table_changed) {

@@ -5,6 +5,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mmhip.h"
@@ -54,6 +55,8 @@ struct mmhip_invocation {
     std::vector<void *> native_maps;       // float4 maps produced by native filters
     std::vector<mm::HNativeRec> native_memo;   // args of the call that produced native_maps[k]
     std::vector<unsigned long long> native_memo_gen;
+    std::vector<std::pair<int, int>> native_rows;   // rows of native_maps[k] that are valid
+    int native_row_margin = -1;                     // mmhip_set_native_row_margin
     unsigned long long input_generation = 1;
     char *d_xy = nullptr;
     int xy_cap = 0;

@@ -5,8 +5,14 @@ The reference parallelises a render by contiguous row bands on threads
 here across ranks.  Pixels are independent, so the data path needs no collective:
 every rank holds a replica of the (small) input image and renders rows
 [H*g/G, H*(g+1)/G) of the output into its own HBM.  Only gathering the finished stripes
-on one rank (for writing a file) communicates, and only the Gaussian blur's vertical
-pass needs halo rows from its neighbours.
+on one rank (for writing a file) communicates.
+
+The Gaussian blur's vertical pass couples rows, but because the input is replicated the halo
+a stripe needs (ceil(22.7 sigma) rows above and below, after which the recurrences' start-up
+error is below half an ulp of their f64 sums) is re-rendered locally instead of exchanged:
+`native_row_margin` lets a stripe render fill only its own window of the blur map
+(native_filters.hip gaussian_blur; tests/test_gpu_parity.py::
+test_gauss_row_stripes_with_local_halo_equal_full_frame checks bit-equality with the full frame).
 """
 
 
@@ -17,11 +23,15 @@ def stripe_rows(height, rank, world):
     return lo, hi
 
 
-def render_stripe(inv, out_ptr, rank, world, t=0.0, frame=0, stream=0, bpp=4):
+def render_stripe(inv, out_ptr, rank, world, t=0.0, frame=0, stream=0, bpp=4, native_row_margin=None):
     """Renders this rank's stripe of the frame into device memory at out_ptr (first row of
     the stripe).  Coordinates are computed from absolute rows, so the union of all ranks'
-    stripes is bit-identical to a single-GPU render."""
+    stripes is bit-identical to a single-GPU render.  `native_row_margin` (rows, or None):
+    for filters that sample a native-filter map no further than that many rows from the output
+    row -- 0 for `blurred(xy)` -- the map is computed for the stripe's window only."""
     lo, hi = stripe_rows(inv.height, rank, world)
+    if native_row_margin is not None:
+        inv.set_native_row_margin(native_row_margin)
     inv.render_rows(out_ptr, lo, hi, t=t, frame=frame, bpp=bpp, stream=stream)
     return lo, hi
 

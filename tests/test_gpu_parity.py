@@ -108,6 +108,40 @@ def test_gauss_iir_float_map_is_bit_exact(size):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
 
 
+def test_gauss_row_stripes_with_local_halo_equal_full_frame():
+    """Multi-GPU striping of a blurred frame: each stripe's render fills only its rows
+    of the blur map plus a halo of ceil(22.7 sigma) rows computed locally from the replicated
+    input -- no exchange -- and must reproduce the full-frame result bit for bit (float map)."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = 640, 1500
+    img = W.synthetic_image(w, h, seed=13)
+    uv = {"hdev": 2 * 3.0 / (w - 1), "vdev": 2 * 2.5 / (h - 1)}       # sigma 3 px / 2.5 px -> halo 59 rows
+    flt = mm.Filter(W.GAUSS_DIRECT)
+
+    def render(stripes, margin):
+        inv = flt.invoke(w, h)
+        for k, v in uv.items():
+            inv.set(k, v)
+        inv.set_image("in", img)
+        inv.set_native_row_margin(margin)
+        dev = lib().mmhip_device_alloc(w * h * 16)
+        try:
+            for lo, hi in stripes:
+                inv.render_rows(dev + lo * w * 16, lo, hi, floatmap=True)
+            inv.sync()
+            out = np.empty((h, w, 4), np.float32)
+            assert lib().mmhip_copy_to_host(out.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * 16) == 0
+        finally:
+            lib().mmhip_device_free(C.c_void_p(dev))
+        return out
+
+    full = render([(0, h)], -1)
+    from mathmap_amd.striping import stripe_rows
+    striped = render([stripe_rows(h, g, 4) for g in range(4)], 0)
+    assert np.array_equal(full.view(np.uint32), striped.view(np.uint32)), np.abs(full - striped).max()
+
+
 def test_nearest_sampling_matches_oracle():
     w, h = 300, 200
     img = W.synthetic_image(w, h, seed=5)
