@@ -160,9 +160,9 @@ struct Generator {
                            std::to_string(k) + ", 3, mm_narg(" + prim(r.args[0], sl) + "), mm_narg(" + prim(r.args[1], sl) +
                            "), mm_narg(" + prim(r.args[2], sl) + "), mm_narg(0))";
                 }
-                for (const char *bad : {"RAND", "ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P",
-                                        "ELL_INT_D", "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ", "ELL_JAC",
-                                        "SOLVE_LINEAR_2", "SOLVE_LINEAR_3", "SOLVE_POLY_2", "SOLVE_POLY_3",
+                for (const char *bad : {"ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P",
+                                        "ELL_INT_D", "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ",
+                                        "SOLVE_POLY_2", "SOLVE_POLY_3",
                                         "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH", "START_DEBUG_TUPLE",
                                         "SET_DEBUG_TUPLE_DATA", "OUTPUT_TUPLE"})
                     if (!strcmp(cn, bad)) throw CompileError(std::string("HIP backend: op ") + cn + " is not supported yet");
@@ -467,6 +467,7 @@ struct Generator {
         // float-argument sin/cos (mm_fastmath.h), the same text the host verifier compiles; it
         // precedes the device prelude, whose complex functions use mmf_sincos_d
         out << "#define MMF_FN static __device__ __forceinline__\n#define MMF_CONST_TABLE static __device__ const\n"
+               "#define MMG_FN static __device__\n"
                "#define MMF_FMA(a, b, c) __builtin_fma((a), (b), (c))\n#define MMF_RINT(a) __builtin_rint((a))\n"
                "#define MMF_FABSF(a) __builtin_fabsf((a))\n#define MMF_FABS(a) __builtin_fabs((a))\n"
                "#define MMF_SIN_SLOW(a) sin((a))\n#define MMF_COS_SLOW(a) cos((a))\n"
@@ -556,7 +557,8 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
             out << "  const int rl = row0;   // A.ppt is 1 for this kernel (KernelSource::single_pixel)\n"
                    "  if (rl >= A.num_rows) return;\n"
                    "  const float y = A.ytab[rl];    // CALC_VIRTUAL_Y(first_row + rl, ...), once per row by the prologue\n"
-                   "  (void)y;\n";
+                   "  unsigned mm_rand_ctr = 0;      // RAND call number within this pixel\n"
+                   "  (void)y; (void)mm_rand_ctr;\n";
             decls(pix_defs, "  ");
             stmts(code.body, PIXEL, "  ");
             out << "  mm_tup<4> rt;\n";
@@ -586,7 +588,10 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                 << I << "  }\n"
                 << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
                 << I << "    const float y = mm_y[mm_u];    // CALC_VIRTUAL_Y(first_row + rl, ...), once per row by the prologue\n"
-                << I << "    (void)y;\n";
+                << I << "    const int rl_u = row0 + (mm_p + mm_u) * MM_TILE_H;\n"
+                << I << "    const int rl = rl_u < A.num_rows ? rl_u : A.num_rows - 1;\n"
+                << I << "    unsigned mm_rand_ctr = 0;      // RAND call number within this pixel\n"
+                << I << "    (void)y; (void)rl; (void)mm_rand_ctr;\n";
             decls(pix_defs, (I + "    ").c_str());
             stmts(code.body, PIXEL, (I + "    ").c_str());
             for (int i = 0; i < 4; ++i)

@@ -130,6 +130,40 @@ MM_DEV double mm_acosh(double a) { return acosh(a); }
 MM_DEV double mm_atanh(double a) { return atanh(a); }
 MM_DEV double mm_floor(double a) { return floor(a); }
 MM_DEV double mm_ceil(double a) { return ceil(a); }
+// GSL / GLib operators (mm_gslmath.h, restated; parity unpinned)
+MM_DEV mm_tup<2> mm_solve_linear_2(const mm_tup<4> &m, const mm_tup<2> &v) {
+    double A[4], x[2];
+    for (int i = 0; i < 4; ++i) A[i] = m.v[i];
+    x[0] = v.v[0]; x[1] = v.v[1];
+    mmg_hh_svx(2, A, x);
+    mm_tup<2> r;
+    r.v[0] = (float)x[0]; r.v[1] = (float)x[1];
+    return r;
+}
+MM_DEV mm_tup<3> mm_solve_linear_3(const mm_tup<9> &m, const mm_tup<3> &v) {
+    double A[9], x[3];
+    for (int i = 0; i < 9; ++i) A[i] = m.v[i];
+    for (int i = 0; i < 3; ++i) x[i] = v.v[i];
+    mmg_hh_svx(3, A, x);
+    mm_tup<3> r;
+    for (int i = 0; i < 3; ++i) r.v[i] = (float)x[i];
+    return r;
+}
+MM_DEV mm_tup<3> mm_ell_jac(double u, double m) {
+    double sn, cn, dn;
+    mmg_elljac(u, m, &sn, &cn, &dn);
+    mm_tup<3> r;
+    r.v[0] = (float)sn; r.v[1] = (float)cn; r.v[2] = (float)dn;
+    return r;
+}
+#define SOLVE_LINEAR_2(m, v) (mm_solve_linear_2((m), (v)))
+#define SOLVE_LINEAR_3(m, v) (mm_solve_linear_3((m), (v)))
+#define ELL_JAC(u, m) (mm_ell_jac((u), (m)))
+// g_random_double_range(a, b): u * (b - a) + a in double.  `col`, `rl`, `mm_rand_ctr` are the pixel
+// kernel's locals: absolute pixel position, so the value does not depend on stripes or tiles.
+#define RAND(a, b) \
+    (mmg_rand_unit(col + A.region_x, A.first_row + rl, A.frame, mm_rand_ctr++) * ((double)(b) - (double)(a)) + (double)(a))
+
 MM_DEV double mm_gamma(double a) { return (a > 171.0) ? 0.0 : tgamma(a); }   // opmacros.h:43
 MM_DEV double mm_beta(double a, double b) { return exp(lgamma(a) + lgamma(b) - lgamma(a + b)); }
 

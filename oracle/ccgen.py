@@ -32,9 +32,9 @@ BUILD = os.path.join(HERE, "_build")
 CTYPES = {"int": "int", "float": "float", "complex": "float _Complex", "color": "color_t",
           "curve": "int", "gradient": "int", "image": "mmo_image"}
 
-UNSUPPORTED = {"RAND", "ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P", "ELL_INT_D",
-               "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ", "ELL_JAC", "SOLVE_LINEAR_2",
-               "SOLVE_LINEAR_3", "SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH",
+UNSUPPORTED = {"ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P", "ELL_INT_D",
+               "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ",
+               "SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH",
                }
 NOISE_OPS = {"libnoise_perlin", "libnoise_billow", "libnoise_ridged_multi", "libnoise_voronoi"}
 NOISE_LIB = os.path.join(HERE, "_ref", "libmmnoise.so")
@@ -287,7 +287,8 @@ void mmo_init_frame(const mmo_args *A, void *xyv) {
     for (col = 0; col < A->region_width; ++col) {
       float x = CALC_VIRTUAL_X(col + A->region_x, A->frame_render_width, A->sampling_offset_x);
       float rt[4];
-      (void)x; (void)y;""")
+      unsigned mm_rand_ctr = 0;
+      (void)x; (void)y; (void)mm_rand_ctr;""")
         self.decls(pix_defs, "      ", out)
         self.stmts(ir["body"], False, "      ", out)
         for i, r in enumerate(ir["result"]):

@@ -181,6 +181,43 @@ void mmo_gauss_rle(float *map, int width, int height, float hdev, float vdev);
 void mmo_find_iir_constants(double *n_p, double *n_m, double *d_p, double *d_m, double *bd_p, double *bd_m, float std_dev);
 void mmo_free_memo(mmo_args *A, int nslots);
 float _Complex cgamma(float _Complex z);
+
+/* GSL / GLib operators: GSL and GLib are not in the image -- the same restatement of the published
+ * algorithms the device uses (mathmap_amd/csrc/mm_gslmath.h is included as text: a checker of the
+ * plumbing around them, not an independent oracle).  PARITY UNPINNED for these three. */
+#include "../mathmap_amd/csrc/mm_gslmath.h"
+static inline mmo_tup2 mmo_solve_linear_2(mmo_tup4 m, mmo_tup2 v) {
+    double A4[4], x[2];
+    int i;
+    mmo_tup2 r;
+    for (i = 0; i < 4; ++i) A4[i] = m.v[i];
+    x[0] = v.v[0]; x[1] = v.v[1];
+    mmg_hh_svx(2, A4, x);
+    r.v[0] = x[0]; r.v[1] = x[1];
+    return r;
+}
+static inline mmo_tup3 mmo_solve_linear_3(mmo_tup9 m, mmo_tup3 v) {
+    double A9[9], x[3];
+    int i;
+    mmo_tup3 r;
+    for (i = 0; i < 9; ++i) A9[i] = m.v[i];
+    for (i = 0; i < 3; ++i) x[i] = v.v[i];
+    mmg_hh_svx(3, A9, x);
+    for (i = 0; i < 3; ++i) r.v[i] = x[i];
+    return r;
+}
+static inline mmo_tup3 mmo_ell_jac(double u, double m) {
+    double sn, cn, dn;
+    mmo_tup3 r;
+    mmg_elljac(u, m, &sn, &cn, &dn);
+    r.v[0] = sn; r.v[1] = cn; r.v[2] = dn;
+    return r;
+}
+#define SOLVE_LINEAR_2(m, v) (mmo_solve_linear_2((m), (v)))
+#define SOLVE_LINEAR_3(m, v) (mmo_solve_linear_3((m), (v)))
+#define ELL_JAC(u, m) (mmo_ell_jac((u), (m)))
+#define RAND(a, b) \
+    (mmg_rand_unit(col + A->region_x, row + A->region_y, A->frame, mm_rand_ctr++) * ((double)(b) - (double)(a)) + (double)(a))
 #define gsl_sf_beta(a, b) (exp(lgamma((a)) + lgamma((b)) - lgamma((a) + (b))))   /* GSL absent: parity unpinned */
 
 #endif

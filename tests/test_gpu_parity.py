@@ -413,6 +413,77 @@ def test_specialised_mandelbrot_8192_equals_generic():
     assert np.array_equal(a, b)
 
 
+GSL_PROBES = [
+    # v2 / m2x2 and v3 / m3x3: gsl_linalg_HH_solve (opmacros.h:84-96)
+    ("q = v2:[x + 2, y - 1] / m2x2:[x + 2.5, y, 0.3, y + 1.5]; rgba:[q[0], q[1], q[0], q[1]]", 2),
+    ("q = v3:[x, y, 1] / m3x3:[2 + x, y, 0.1, 0.3, 1.5 + y, x, 0.2, 0.1, 3]; rgba:[q[0], q[1], q[2], q[0]]", 2),
+    ("q = v2:[1, 2] / m2x2:[1, 2, 2, 4]; rgba:[q[0], q[1], 0, 1]", 0),       # singular: x as far as HH_svx got
+    # gsl_sf_elljac_e (opmacros.h:118-126), real and complex argument
+    ("rgba:[ell_jac_sn(x * 3, 0.5), ell_jac_cn(y * 3, 0.3), ell_jac_dn(x * y * 4, 0.8), ell_jac_sn(x, 1.5)]", 4),
+    ("w = ell_jac_cn(ri:[x * 2, y * 2], 0.5); rgba:[w[0], w[1], w[0], w[1]]", 16),
+]
+
+
+@pytest.mark.parametrize("body,max_ulp", GSL_PROBES)
+def test_gsl_operators_match_restatement(body, max_ulp):
+    """SOLVE_LINEAR_2/3 and ELL_JAC: device vs the oracle build of the same restated GSL algorithms
+    (mm_gslmath.h; GSL itself is absent -- parity with the reference is unpinned).  Float-map
+    output; differences come from OCML vs glibc sqrt/sin/cos/hypot inside the algorithms."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = 192, 128
+    flt = mm.Filter("filter probe () %s end" % body)
+    inv = flt.invoke(w, h)
+    dev = lib().mmhip_device_alloc(w * h * 16)
+    try:
+        inv.render_rows(dev, 0, h, floatmap=True)
+        inv.sync()
+        got = np.empty((h, w, 4), np.float32)
+        assert lib().mmhip_copy_to_host(got.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * 16) == 0
+    finally:
+        lib().mmhip_device_free(C.c_void_p(dev))
+    want = CpuFilter(flt.ir_json).render(w, h, floatmap=True)
+    finite = np.isfinite(got) & np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    ulps = np.abs(got[finite].view(np.int32).astype(np.int64) - want[finite].view(np.int32).astype(np.int64))
+    assert ulps.max() <= max_ulp, ulps.max()
+    assert (ulps == 0).mean() > 0.98
+
+
+def test_rand_is_deterministic_and_stripe_invariant():
+    """rand(a, b): a counter-based hash of (column, row, frame, call number) stands in for the
+    reference's clock-seeded global generator (mm_gslmath.h).  Device == oracle build of the same
+    hash, bit for bit; rendering in stripes changes nothing; two calls in one pixel differ; the
+    values fill [a, b)."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = 256, 192
+    flt = mm.Filter("filter r () u = rand(-2, 3); v = rand(0, 1); rgba:[u, v, rand(10, 11), u - v] end")
+    inv = flt.invoke(w, h)
+
+    def grab(stripes):
+        dev = lib().mmhip_device_alloc(w * h * 16)
+        try:
+            for lo, hi in stripes:
+                inv.render_rows(dev + lo * w * 16, lo, hi, floatmap=True)
+            inv.sync()
+            out = np.empty((h, w, 4), np.float32)
+            assert lib().mmhip_copy_to_host(out.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * 16) == 0
+        finally:
+            lib().mmhip_device_free(C.c_void_p(dev))
+        return out
+
+    full = grab([(0, h)])
+    assert np.array_equal(full, grab([(0, 50), (50, 51), (51, h)]))
+    want = CpuFilter(flt.ir_json).render(w, h, floatmap=True)
+    assert np.array_equal(full.view(np.uint32), want.view(np.uint32))
+    u, v, t3 = full[:, :, 0], full[:, :, 1], full[:, :, 2]
+    assert u.min() >= -2 and u.max() < 3 and v.min() >= 0 and v.max() < 1 and t3.min() >= 10 and t3.max() <= 11
+    assert abs(float(u.mean()) - 0.5) < 0.02 and abs(float(v.mean()) - 0.5) < 0.01
+    assert abs(np.corrcoef(u.ravel(), v.ravel())[0, 1]) < 0.02
+    assert abs(np.corrcoef(v[:, :-1].ravel(), v[:, 1:].ravel())[0, 1]) < 0.02
+
+
 def test_curve_and_gradient_user_values(marlene):
     """Curve / gradient LUT user values (APPLY_CURVE / APPLY_GRADIENT, opmacros.h:192-194): default
     ramps and explicitly set tables, HIP vs oracle, bit-exact."""
