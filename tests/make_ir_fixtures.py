@@ -42,6 +42,29 @@ def main():
         manifest.append({"ir": stem + ".json.gz", "golden": golden, "uservals": uv, "needs_image": needs})
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
     print("%d fixtures" % len(manifest))
+    make_example_fixtures()
+
+
+def make_example_fixtures():
+    """The same for every filter under the reference's examples/ (189): IR only, default user
+    values; tests/test_gpu_parity.py::test_reference_examples_on_gpu renders them on the GPU and
+    with the oracle."""
+    import glob
+    out = os.path.join(ROOT, "tests", "golden", "ir_examples")
+    os.makedirs(out, exist_ok=True)
+    names = []
+    for path in sorted(glob.glob("/root/reference/examples/**/*.mm", recursive=True)):
+        rel = os.path.relpath(path, "/root/reference/examples")
+        stem = rel[:-3].replace("/", "__").replace(" ", "_")
+        flt = mm.Filter(open(path, errors="replace").read())
+        if flt.needs_constants:
+            flt = flt.specialized()
+        with open(os.path.join(out, stem + ".json.gz"), "wb") as raw:
+            with gzip.GzipFile(fileobj=raw, mode="wb", compresslevel=9, mtime=0, filename="") as f:
+                f.write(flt.ir_json.encode())
+        names.append(stem)
+    json.dump(names, open(os.path.join(out, "manifest.json"), "w"), indent=1)
+    print("%d example fixtures" % len(names))
 
 
 if __name__ == "__main__":

@@ -584,6 +584,40 @@ def test_recursive_filter_renders_per_depth():
     assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[1], outs[2])
 
 
+def _example_manifest():
+    import json
+    import os
+    from tests.conftest import GOLDEN
+    p = os.path.join(GOLDEN, "ir_examples", "manifest.json")
+    return json.load(open(p)) if os.path.exists(p) else []
+
+
+@pytest.mark.parametrize("stem", _example_manifest())
+def test_reference_examples_on_gpu(stem, marlene):
+    """Every filter under the reference's examples/ (189; IR fixtures, default user values, every
+    image input bound to the 128x128 corner of marlene.png, t = 0.3): HIP vs oracle.
+    <= 1 LSB; filters with discontinuities (modulo, comparisons on libm results, noise lattice
+    lookups) may differ further on up to 0.5 % of the values where OCML and glibc differ by a
+    float ulp."""
+    import gzip
+    import os
+    from tests.conftest import GOLDEN
+    ir = gzip.open(os.path.join(GOLDEN, "ir_examples", stem + ".json.gz"), "rt").read()
+    flt = mm.Filter("", ir_json=ir)
+    w = h = 128
+    img = np.ascontiguousarray(marlene[:h, :w])
+    inv = flt.invoke(w, h)
+    images = {}
+    for u in flt.uservals:
+        if u["kind"] == mm.api.UV_IMAGE:
+            inv.set_image(u["name"], img)
+            images[u["name"]] = img
+    got = inv.render(t=0.3)
+    want = CpuFilter(ir).render(w, h, images=images, t=0.3)
+    mx, nd, n1 = stats(got, want)
+    assert mx <= 1 or n1 < 0.005 * want.size, "%s: max %d, %d differ, %d by more than 1" % (stem, mx, nd, n1)
+
+
 def _ir_manifest():
     import json
     import os
