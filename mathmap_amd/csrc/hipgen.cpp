@@ -203,6 +203,8 @@ struct Generator {
                 if (opt.fast_math_exact && lhs && lhs->type == Ty::Float && r.args.size() == 1 && r.args[0].type() == Ty::Float) {
                     if (!strcmp(cn, "sin")) name = "mmf_sin_f32";
                     else if (!strcmp(cn, "cos")) name = "mmf_cos_f32";
+                    else if (!strcmp(cn, "exp")) name = "mmf_exp_f32";
+                    else if (!strcmp(cn, "log")) name = "mmf_log_f32";
                 }
                 std::string s = name + "(";
                 for (size_t i = 0; i < r.args.size(); ++i) s += (i ? "," : "") + prim(r.args[i], sl);
@@ -471,6 +473,7 @@ struct Generator {
                "#define MMF_FMA(a, b, c) __builtin_fma((a), (b), (c))\n#define MMF_RINT(a) __builtin_rint((a))\n"
                "#define MMF_FABSF(a) __builtin_fabsf((a))\n#define MMF_FABS(a) __builtin_fabs((a))\n"
                "#define MMF_SIN_SLOW(a) sin((a))\n#define MMF_COS_SLOW(a) cos((a))\n"
+               "#define MMF_LDEXP(a, e) __builtin_ldexp((a), (e))\n#define MMF_EXP_SLOW(a) exp((a))\n#define MMF_LOG_SLOW(a) log((a))\n"
             << device_fastmath_prelude() << "\n";
         out << device_prelude() << "\n";
         if (uses_noise(code.body)) {
@@ -519,6 +522,8 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
             out << "  *(" << ctype(v->var) << " *)(XY + " << transfer_off[v] << ") = " << vname(v) << ";\n";
         out << "}\n\n";
         // ---- pixel kernel ----
+        // experiment hook: ask the register allocator for a minimum occupancy (waves per SIMD)
+        if (const char *e = getenv("MMHIP_WAVES_PER_EU")) out << "__attribute__((amdgpu_waves_per_eu(" << atoi(e) << "))) ";
         out << R"(extern "C" __global__ void __launch_bounds__(256) mm_pixels(mm_args A, const char *__restrict__ XY) {
   MM_INTERNALS
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs; give each

@@ -196,9 +196,9 @@ MM_DEV mm_dc mm_dcdiv(mm_dc a, mm_dc b) {
     double d = b.re * b.re + b.im * b.im;
     return mm_dcmake((a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d);
 }
-MM_DEV mm_dc mm_dclog(mm_dc z) { return mm_dcmake(log(hypot(z.re, z.im)), atan2(z.im, z.re)); }
+MM_DEV mm_dc mm_dclog(mm_dc z) { return mm_dcmake(mmf_log_any(hypot(z.re, z.im)), atan2(z.im, z.re)); }
 MM_DEV mm_dc mm_dcexp(mm_dc z) {
-    double e = exp(z.re), s, c;
+    double e = mmf_exp_any(z.re), s, c;
     mmf_sincos_d(z.im, &s, &c);
     if (z.im == 0.0) return mm_dcmake(e, z.im);
     return mm_dcmake(e * c, e * s);

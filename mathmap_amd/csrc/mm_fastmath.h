@@ -98,4 +98,83 @@ MMF_FN void mmf_sincos_d(double xd, double *sn, double *cs) {
     *cs = c + MMF_FMA(c, cm1, -(s * sy));
 }
 
+// ---- exp and log of a float argument ---------------------------------------------------------
+// (float)exp((double)x) and (float)log((double)x), verified like sin/cos against glibc for every
+// float in the fast range (exp: |x| <= 700, the rest under/overflows even in double and goes to
+// the platform function; log: every positive finite float).  Tables are double-double.
+#ifndef MMF_LDEXP
+#define MMF_LDEXP(a, e) ldexp((a), (e))
+#define MMF_EXP_SLOW(a) exp((a))
+#define MMF_LOG_SLOW(a) log((a))
+#endif
+
+MMF_CONST_TABLE double mmf_exp_table[128] = MMF_EXP_TABLE;
+MMF_CONST_TABLE double mmf_log_table[387] = MMF_LOG_TABLE;
+
+// exp(xd) for |xd| <= 700: x = k ln2/64 + r, |r| <= ln2/128; 2^(k/64) from the table, exp(r) - 1
+// by its Taylor polynomial (r^7/5040 < 2^-65 of the result).
+MMF_FN double mmf_exp_d(double xd) {
+    const double kd = MMF_RINT(xd * MMF_INV_LN2O64);
+    const int k = (int)kd;
+    double r = MMF_FMA(kd, -MMF_LN2O64_HI, xd);
+    r = MMF_FMA(kd, -MMF_LN2O64_LO, r);
+    double q = MMF_FMA(r, 1.0 / 720.0, 1.0 / 120.0);
+    q = MMF_FMA(r, q, 1.0 / 24.0);
+    q = MMF_FMA(r, q, 1.0 / 6.0);
+    q = MMF_FMA(r, q, 0.5);
+    const double p = MMF_FMA(r * r, q, r);                   // exp(r) - 1
+    const double th = mmf_exp_table[2 * (k & 63)], tl = mmf_exp_table[2 * (k & 63) + 1];
+    const double res = th + MMF_FMA(th, p, tl);
+    return MMF_LDEXP(res, k >> 6);
+}
+
+MMF_FN float mmf_exp_f32(float x) {
+    if (!(MMF_FABSF(x) <= 700.0f)) return (float)MMF_EXP_SLOW((double)x);
+    return (float)mmf_exp_d((double)x);
+}
+
+// log(xd), xd a positive, finite, normal double: xd = 2^e m, m in [1, 2); i = round((m-1) 128),
+// c = 1 + i/128 (i = 128 folds into the next binade, so x near 1 has c = 1 and r = x - 1
+// exactly); log m = -log(invc) + log1p(m invc - 1) with invc = fl(1/c) and the table holding
+// -log(invc) for that rounded value.
+MMF_FN double mmf_log_d(double xd) {
+    union { double d; unsigned long long u; } b;
+    b.d = xd;
+    int e = (int)((b.u >> 52) & 0x7ff) - 1023;
+    b.u = (b.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = b.d;
+    int i = (int)MMF_RINT((m - 1.0) * 128.0);
+    if (i == 128) {
+        m *= 0.5;
+        e += 1;
+        i = 0;
+    }
+    const double invc = mmf_log_table[3 * i], lch = mmf_log_table[3 * i + 1], lcl = mmf_log_table[3 * i + 2];
+    const double r = MMF_FMA(m, invc, -1.0);
+    // log1p(r) - r = r^2 (-1/2 + r (1/3 + r (-1/4 + r (1/5 + r (-1/6 + r/7)))))
+    double q = MMF_FMA(r, 1.0 / 7.0, -1.0 / 6.0);
+    q = MMF_FMA(r, q, 0.2);
+    q = MMF_FMA(r, q, -0.25);
+    q = MMF_FMA(r, q, 1.0 / 3.0);
+    q = MMF_FMA(r, q, -0.5);
+    const double ed = (double)e;
+    const double s = ed * MMF_LN2_HI;                         // exact: 42 x 8 bits
+    const double t = s + lch;
+    const double err = (s - t) + lch;                         // Fast2Sum: |s| >= |lch| whenever e != 0
+    const double lo = MMF_FMA(r * r, q, MMF_FMA(ed, MMF_LN2_LO, lcl) + err);
+    return t + (lo + r);
+}
+
+MMF_FN float mmf_log_f32(float x) {
+    // positive finite floats only (denormals included: they are normal doubles)
+    if (!(x > 0.0f && x <= 3.40282346638528859812e38f)) return (float)MMF_LOG_SLOW((double)x);
+    return (float)mmf_log_d((double)x);
+}
+
+// Double-in, double-out variants with the range tests, for the float-complex functions.
+MMF_FN double mmf_exp_any(double xd) { return (MMF_FABS(xd) <= 700.0) ? mmf_exp_d(xd) : MMF_EXP_SLOW(xd); }
+MMF_FN double mmf_log_any(double xd) {
+    return (xd >= 2.2250738585072014e-308 && xd <= 1.7976931348623157e308) ? mmf_log_d(xd) : MMF_LOG_SLOW(xd);
+}
+
 #endif  // MM_FASTMATH_H

@@ -304,7 +304,8 @@ def test_byte_to_unit_newton_step_identity():
 
 def test_fastmath_sin_cos_equal_glibc_sampled():
     """mm_fastmath.h (the text the JIT prelude embeds) against glibc's (float)sin((double)x) /
-    (float)cos((double)x): every 97th float below 2^22, both signs -- 26 M arguments.  The
+    (float)cos((double)x): every 97th float below 2^22, both signs -- 26 M arguments; likewise exp
+    (|x| <= 700) and log (all positive floats).  The
     exhaustive run (stride 1, 2.5e9 arguments, 0 mismatches) is recorded in
     profiles/r01_verify_fastmath.json; tools/verify_fastmath.c is the checker."""
     import subprocess
@@ -315,7 +316,8 @@ def test_fastmath_sin_cos_equal_glibc_sampled():
     r = subprocess.run([exe, "97"], stdout=subprocess.PIPE, text=True)
     rep = json.loads(r.stdout)
     assert r.returncode == 0 and rep["sin_mismatches"] == 0 and rep["cos_mismatches"] == 0, rep
-    assert rep["checked"] > 25_000_000
+    assert rep["exp_mismatches"] == 0 and rep["log_mismatches"] == 0, rep
+    assert rep["checked"] > 25_000_000 and rep["exp_checked"] > 20_000_000 and rep["log_checked"] > 20_000_000
 
 
 def test_sqrt_less_power_of_two_identity():

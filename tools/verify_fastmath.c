@@ -20,7 +20,7 @@
 enum { NTHREADS = 8 };
 static uint32_t stride = 1;
 static uint32_t limit_bits;
-typedef struct { uint64_t checked, bad_sin, bad_cos; uint32_t first_bad; int tid; } acc_t;
+typedef struct { uint64_t checked, bad_sin, bad_cos, checked_exp, bad_exp, checked_log, bad_log; uint32_t first_bad, first_bad_exp, first_bad_log; int tid; } acc_t;
 
 static inline uint32_t bits_of(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float float_of(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -37,6 +37,19 @@ static void *worker(void *p) {
             ++a->checked;
         }
     }
+    /* exp: every float with |x| <= 700 (both signs); log: every positive finite float */
+    const uint32_t exp_limit = bits_of(700.0f), log_limit = 0x7f800000u;
+    for (uint64_t u = (uint64_t)a->tid * stride; u <= exp_limit; u += (uint64_t)NTHREADS * stride)
+        for (int sign = 0; sign < 2; ++sign) {
+            const float x = float_of((uint32_t)u | ((uint32_t)sign << 31));
+            if (bits_of((float)exp((double)x)) != bits_of(mmf_exp_f32(x))) { if (!a->bad_exp) a->first_bad_exp = bits_of(x); ++a->bad_exp; }
+            ++a->checked_exp;
+        }
+    for (uint64_t u = 1 + (uint64_t)a->tid * stride; u < log_limit; u += (uint64_t)NTHREADS * stride) {
+        const float x = float_of((uint32_t)u);
+        if (bits_of((float)log((double)x)) != bits_of(mmf_log_f32(x))) { if (!a->bad_log) a->first_bad_log = bits_of(x); ++a->bad_log; }
+        ++a->checked_log;
+    }
     return NULL;
 }
 
@@ -48,14 +61,20 @@ int main(int argc, char **argv) {
     acc_t acc[NTHREADS];
     memset(acc, 0, sizeof acc);
     for (int i = 0; i < NTHREADS; ++i) { acc[i].tid = i; pthread_create(&th[i], NULL, worker, &acc[i]); }
-    uint64_t checked = 0, bs = 0, bc = 0;
-    uint32_t first = 0;
+    uint64_t checked = 0, bs = 0, bc = 0, ce = 0, be = 0, cl = 0, bl = 0;
+    uint32_t first = 0, fe = 0, fl = 0;
     for (int i = 0; i < NTHREADS; ++i) {
         pthread_join(th[i], NULL);
         checked += acc[i].checked; bs += acc[i].bad_sin; bc += acc[i].bad_cos;
+        ce += acc[i].checked_exp; be += acc[i].bad_exp; cl += acc[i].checked_log; bl += acc[i].bad_log;
         if (!first && (acc[i].bad_sin || acc[i].bad_cos)) first = acc[i].first_bad;
+        if (!fe && acc[i].bad_exp) fe = acc[i].first_bad_exp;
+        if (!fl && acc[i].bad_log) fl = acc[i].first_bad_log;
     }
-    printf("{\"checked\": %llu, \"stride\": %u, \"sin_mismatches\": %llu, \"cos_mismatches\": %llu, \"first_bad_bits\": \"0x%08x\"}\n",
-           (unsigned long long)checked, stride, (unsigned long long)bs, (unsigned long long)bc, first);
-    return (bs || bc) ? 1 : 0;
+    printf("{\"checked\": %llu, \"stride\": %u, \"sin_mismatches\": %llu, \"cos_mismatches\": %llu, \"first_bad_bits\": \"0x%08x\", "
+           "\"exp_checked\": %llu, \"exp_mismatches\": %llu, \"exp_first_bad_bits\": \"0x%08x\", "
+           "\"log_checked\": %llu, \"log_mismatches\": %llu, \"log_first_bad_bits\": \"0x%08x\"}\n",
+           (unsigned long long)checked, stride, (unsigned long long)bs, (unsigned long long)bc, first,
+           (unsigned long long)ce, (unsigned long long)be, fe, (unsigned long long)cl, (unsigned long long)bl, fl);
+    return (bs || bc || be || bl) ? 1 : 0;
 }
