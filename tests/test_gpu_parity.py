@@ -584,6 +584,33 @@ def test_recursive_filter_renders_per_depth():
     assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("seed", range(80))
+def test_random_filters_hip_vs_oracle_and_specialised_vs_generic(seed):
+    """Differential fuzzing (tests/fuzz_filters.py): a random filter with loops, conditionals, libm
+    calls and image fetches is printed twice from the same IR -- as a HIP kernel (prologue/pixel
+    split, hoisting, unrolled hot variant) and as C by the oracle -- and must agree within 1 LSB
+    (up to 1 % of the values may differ more: comparisons on libm results).  The user-value
+    specialised kernel must equal the generic one byte for byte."""
+    from tests.fuzz_filters import make_filter
+    src, needs = make_filter(seed)
+    w, h = 96, 64
+    img = W.synthetic_image(w, h, seed=1)
+    uv = {"k": 5, "m": 1.3}
+    outs = []
+    for spec in (False, True):
+        flt = mm.Filter(src, specialize=spec)
+        inv = flt.invoke(w, h)
+        for k, v in uv.items():
+            inv.set(k, v)
+        if needs:
+            inv.set_image("in", img)
+        outs.append(inv.render(t=0.4))
+    assert np.array_equal(outs[0], outs[1]), "specialised kernel differs from the generic one"
+    want = CpuFilter(mm.Filter(src).ir_json).render(w, h, uservals=uv, images={"in": img} if needs else {}, t=0.4)
+    mx, nd, n1 = stats(outs[0], want)
+    assert mx <= 1 or n1 < 0.01 * want.size, "seed %d: max %d, %d differ, %d by more than 1\n%s" % (seed, mx, nd, n1, src)
+
+
 def _example_manifest():
     import json
     import os
