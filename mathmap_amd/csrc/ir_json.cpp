@@ -261,6 +261,10 @@ extern "C" mmhip_filter *mmhip_compile_ir_json(const char *json, const mmhip_opt
         }
         std::string err;
         if (!mmhip_filter_finalize(f, ko, &err)) throw mm::CompileError(err);
+        if (opts) {
+            f->opts = *opts;
+            f->specialize = opts->specialize_uservals != 0;     // per-value-set variants from the IR itself
+        }
     } catch (const std::exception &e) {
         g_mmhip_err = e.what();
         mmhip_filter_free(f);

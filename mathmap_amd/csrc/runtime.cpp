@@ -560,12 +560,47 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
     return 0;
 }
 
+// Specialisation of a filter that has no source text (IR imported through the reference-ABI tier or
+// mmhip_compile_ir_json): reload its own IR dump, replace the scalar USERVAL_*_ACCESS reads by the
+// literals, and run the same constant propagation / folding as the source-level variant.
+static void bake_uservals(Block &b, const std::map<int, Primary> &consts) {
+    for (Stmt *st : b) {
+        if (st->kind == Stmt::Assign && st->rhs.kind == Rhs::Op && st->rhs.args.size() == 1 &&
+            st->rhs.args[0].kind == Primary::IntConst) {
+            const char *n = st->rhs.op->cname;
+            if (!strcmp(n, "USERVAL_INT_ACCESS") || !strcmp(n, "USERVAL_FLOAT_ACCESS") || !strcmp(n, "USERVAL_BOOL_ACCESS")) {
+                auto it = consts.find(st->rhs.args[0].i);
+                if (it != consts.end()) st->rhs = Rhs::P(it->second);
+            }
+        }
+        if (st->kind == Stmt::If) { bake_uservals(st->then_, consts); bake_uservals(st->else_, consts); }
+        if (st->kind == Stmt::While) bake_uservals(st->body, consts);
+    }
+}
+
+static mmhip_filter *compile_ir_specialized(const mmhip_filter *f, const std::map<int, Primary> &consts) {
+    mmhip_filter *sp = mmhip_filter_new_empty();
+    try {
+        sp->code.reset(new FilterCode());
+        load_ir_json(sp->module, *sp->code, f->ir_json.c_str());
+        bake_uservals(sp->code->body, consts);
+        specialize_constants(*sp->code);
+        std::string err;
+        if (!mmhip_filter_finalize(sp, f->kopt, &err)) throw CompileError(err);
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        mmhip_filter_free(sp);
+        return nullptr;
+    }
+    return sp;
+}
+
 // The kernel set to launch: the generic filter, or -- with options.specialize_uservals -- a
 // variant with the current scalar user values baked in as literals (built on first use per
 // value set, cached on the filter and on disk through the hiprtc cache).
 static mmhip_filter *active_filter(mmhip_invocation *inv) {
     mmhip_filter *f = inv->f;
-    if (!f->specialize || !f->ks.natives.empty() || f->source.empty()) return f;
+    if (!f->specialize || !f->ks.natives.empty() || (f->source.empty() && f->ir_json.empty())) return f;
     g_err.clear();
     const auto &uvs = f->module.main->uservals;
     std::string key;
@@ -579,9 +614,13 @@ static mmhip_filter *active_filter(mmhip_invocation *inv) {
     if (consts.empty()) return f;
     auto it = f->spec_cache.find(key);
     if (it != f->spec_cache.end()) return it->second ? it->second : f;
+    // a host that changes values on every render (interactive sliders) should not pay a JIT each
+    // time: build the variant on the spec_min_uses-th render with the same values
+    if (!f->deferred && ++f->spec_uses[key] < f->spec_min_uses) return f;
+    f->spec_uses.erase(key);
     mmhip_options o = f->opts;
     o.specialize_uservals = 0;
-    mmhip_filter *sp = compile_source(f->source.c_str(), &o, &consts);
+    mmhip_filter *sp = f->source.empty() ? compile_ir_specialized(f, consts) : compile_source(f->source.c_str(), &o, &consts);
     if (sp && mmhip_filter_jit(sp, 1) < 0) { mmhip_filter_free(sp); sp = nullptr; }
     f->spec_cache[key] = sp;          // nullptr = fall back to the generic kernel for this value set
     return sp ? sp : f;

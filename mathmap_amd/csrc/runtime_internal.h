@@ -14,6 +14,8 @@
 #include "mm_host_abi.h"
 #include "native_filters.h"
 
+namespace mm { void load_ir_json(Module &mod, FilterCode &code, const char *json); }   // ir_json.cpp
+
 struct mmhip_filter {
     mm::Module module;
     std::unique_ptr<mm::FilterCode> code;
@@ -31,6 +33,8 @@ struct mmhip_filter {
     mmhip_options opts{};
     bool specialize = false;
     std::map<std::string, mmhip_filter *> spec_cache;
+    std::map<std::string, int> spec_uses;     // renders seen per value set that has no variant yet
+    int spec_min_uses = 1;                    // build the variant on this many-th render with one value set
     // a filter that only compiles with its scalar user values baked in (recursion whose depth
     // they control): no generic code/kernels, every render goes through spec_cache
     bool deferred = false;

@@ -406,6 +406,27 @@ def test_userval_specialisation_is_bit_identical(name, uv):
     assert first.shape == special.shape
 
 
+def test_ir_origin_filters_specialise_too():
+    """A filter that arrives as IR (reference-ABI tier, mmhip_compile_ir_json) has no source to
+    re-lower; its variants are built from its own IR dump (bake_uservals + the same constant
+    propagation) and must equal the generic kernel byte for byte."""
+    w, h = 320, 200
+    img = W.synthetic_image(w, h, seed=4)
+    for name, uv in (("mandelbrot", {"num_iterations": 40, "pj": 0.2}), ("pond", {"height": 0.1}), ("droste", {})):
+        src = W.ALL[name]
+        ir = mm.Filter(src).ir_json
+        outs = []
+        for spec in (False, True):
+            flt = mm.Filter("", ir_json=ir, specialize=spec)
+            inv = flt.invoke(w, h)
+            for k, v in uv.items():
+                inv.set(k, v)
+            if "image in" in src:
+                inv.set_image("in", img)
+            outs.append(inv.render(t=0.2))
+        assert np.array_equal(outs[0], outs[1]), name
+
+
 def test_specialised_mandelbrot_8192_equals_generic():
     w = h = 8192
     a = mm.Filter(W.MANDELBROT).invoke(w, h).render()
