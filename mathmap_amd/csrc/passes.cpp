@@ -150,12 +150,113 @@ bool eliminate_dead_code(FilterCode &code) {
     return any;
 }
 
+// ---------------------------------------------------------------------------
+// Loop-carried common subexpressions
+// ---------------------------------------------------------------------------
+// A `while` body that starts by computing op(phi values) and ends (before the back edge) by
+// computing the same op on the values those phis receive computes every such value twice: at
+// the end of iteration i and again at the start of iteration i+1.  Mandelbrot's escape test
+// |z'|^2 = a'^2 + b'^2 and the next z'^2 = (a'^2 - b'^2, 2a'b') share both squares this way.
+// The op at the top is pure, so it is replaced by a new entry phi
+//     s = phi(op(entry values) [materialised before the loop], t)   with t the bottom computation.
+// Value-preserving by construction: the same operator on the same operand values.
+namespace {
+
+bool same_primary(const Primary &a, const Primary &b) {
+    if (a.kind != b.kind) return false;
+    switch (a.kind) {
+        case Primary::Val: return a.value == b.value;
+        case Primary::IntConst: return a.i == b.i;
+        case Primary::FloatConst: return std::memcmp(&a.f, &b.f, sizeof a.f) == 0;
+        default: return false;
+    }
+}
+
+bool loop_cse_block(FilterCode &code, Block &blk) {
+    bool changed = false;
+    for (size_t wi = 0; wi < blk.size(); ++wi) {
+        Stmt *w = blk[wi];
+        if (w->kind == Stmt::If) { changed |= loop_cse_block(code, w->then_); changed |= loop_cse_block(code, w->else_); }
+        if (w->kind != Stmt::While) continue;
+        changed |= loop_cse_block(code, w->body);
+        std::map<const Value *, Stmt *> phi_of;
+        for (Stmt *ph : w->phis) phi_of[ph->lhs] = ph;
+        std::set<const Value *> defined_in_body;
+        for_each_stmt(w->body, [&](Stmt *s) { if (s->lhs) defined_in_body.insert(s->lhs); });
+        for (size_t si = 0; si < w->body.size(); ++si) {
+            Stmt *s = w->body[si];
+            if (s->kind != Stmt::Assign || s->rhs.kind != Rhs::Op || !s->rhs.op->pure) continue;
+            const Ty ty = s->lhs->var->type;
+            if (ty != Ty::Int && ty != Ty::Float) continue;
+            // operands: loop phis (at least one), constants, or values defined outside the loop
+            bool ok = true, any_phi = false;
+            std::vector<Primary> back = s->rhs.args, entry = s->rhs.args;
+            for (size_t a = 0; a < s->rhs.args.size() && ok; ++a) {
+                const Primary &p = s->rhs.args[a];
+                if (p.kind != Primary::Val) { ok = p.kind == Primary::IntConst || p.kind == Primary::FloatConst; continue; }
+                auto it = phi_of.find(p.value);
+                if (it != phi_of.end()) {
+                    if (it->second->rhs.kind != Rhs::Prim || it->second->rhs2.kind != Rhs::Prim) { ok = false; break; }
+                    entry[a] = it->second->rhs.prim;
+                    back[a] = it->second->rhs2.prim;
+                    any_phi = true;
+                } else if (defined_in_body.count(p.value))
+                    ok = false;
+            }
+            if (!ok || !any_phi) continue;
+            // the same op on the back-edge values, at the top level of the body (runs every iteration)
+            Stmt *t = nullptr;
+            for (size_t ti = 0; ti < w->body.size() && !t; ++ti) {
+                Stmt *c = w->body[ti];
+                if (c == s || c->kind != Stmt::Assign || c->rhs.kind != Rhs::Op || c->rhs.op != s->rhs.op) continue;
+                if (c->lhs->var->type != ty || c->rhs.args.size() != back.size()) continue;
+                bool eq = true;
+                for (size_t a = 0; a < back.size() && eq; ++a) eq = same_primary(c->rhs.args[a], back[a]);
+                if (eq) t = c;
+            }
+            if (!t) continue;
+            // u = op(entry values), once before the loop
+            Stmt *u = code.new_stmt(Stmt::Assign);
+            u->lhs = code.new_value(code.new_var(ty));
+            u->lhs->def = u;
+            u->rhs = Rhs::O(s->rhs.op, entry);
+            u->parent = w->parent;
+            blk.insert(blk.begin() + wi, u);
+            ++wi;
+            // s becomes an entry phi of the loop
+            s->kind = Stmt::Phi;
+            s->rhs = Rhs::V(u->lhs);
+            s->rhs2 = Rhs::V(t->lhs);
+            s->old_value = u->lhs;
+            s->parent = w;
+            w->body.erase(w->body.begin() + si);
+            --si;
+            w->phis.push_back(s);
+            phi_of[s->lhs] = s;
+            changed = true;
+        }
+    }
+    return changed;
+}
+
+}  // namespace
+
+bool loop_carried_cse(FilterCode &code) { return loop_cse_block(code, code.body); }
+
 void optimize(FilterCode &code) {
     propagate_types(code);
     for (int i = 0; i < 20; ++i) {
         bool c = copy_propagate(code);
         c |= eliminate_dead_code(code);
         if (!c) break;
+    }
+    if (loop_carried_cse(code)) {
+        propagate_types(code);
+        for (int i = 0; i < 20; ++i) {
+            bool c = copy_propagate(code);
+            c |= eliminate_dead_code(code);
+            if (!c) break;
+        }
     }
 }
 
