@@ -206,6 +206,10 @@ struct Generator {
                     else if (!strcmp(cn, "exp")) name = "mmf_exp_f32";
                     else if (!strcmp(cn, "log")) name = "mmf_log_f32";
                 }
+                if (opt.fast_math_exact && !strcmp(cn, "hypot") && r.args.size() == 2 && r.args[0].type() == Ty::Float &&
+                    r.args[1].type() == Ty::Float) {
+                    name = "mm_hypot_ff";
+                }
                 std::string s = name + "(";
                 for (size_t i = 0; i < r.args.size(); ++i) s += (i ? "," : "") + prim(r.args[i], sl);
                 return s + ")";
