@@ -303,6 +303,16 @@ struct Generator {
         }
     }
 
+    static bool hoisted_uses_time(const Block &b) {
+        for (const Stmt *s : b) {
+            if (s->hoisted && s->kind == Stmt::Assign && s->rhs.kind == Rhs::Internal && (s->rhs.internal == "t" || s->rhs.internal == "frame"))
+                return true;
+            if (s->kind == Stmt::If && (hoisted_uses_time(s->then_) || hoisted_uses_time(s->else_))) return true;
+            if (s->kind == Stmt::While && hoisted_uses_time(s->body)) return true;
+        }
+        return false;
+    }
+
     // pixel-slice statistics for the unroll choice
     static void pixel_stats(const Block &b, int &stmts, int &fetches) {
         for (const Stmt *s : b) {
@@ -513,6 +523,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
     (void)t; (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;
 )";
         // ---- prologue ----
+        ks.prologue_uses_time = hoisted_uses_time(code.body);
         ks.prologue_name = "mm_prologue";
         ks.pixel_name = "mm_pixels";
         out << "extern \"C\" __global__ void __launch_bounds__(256) mm_prologue(mm_args A, char *XY) {\n";

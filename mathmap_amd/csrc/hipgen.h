@@ -35,6 +35,7 @@ struct KernelSource {
     std::vector<NativeCall> natives;
     int tile_w = 16, tile_h = 16;
     int unroll = 1;               // MM_UNROLL of the pixel kernel; the launch's rows per work-item is a multiple
+    bool prologue_uses_time = true;   // frame-constant code reads t or frame: re-run it for every frame
     bool single_pixel = false;    // kernel renders exactly one pixel per work-item: launch with ppt = 1
     std::string key;              // cache key (hash of source)
 };

@@ -510,6 +510,7 @@ static int upload_tables(mmhip_invocation *inv, hipStream_t s) {
     if (inv->d_curves) HIP_TRY(hipMemcpy(inv->d_curves, inv->curves.data(), inv->curves.size() * 4, hipMemcpyHostToDevice));
     if (inv->d_gradients) HIP_TRY(hipMemcpy(inv->d_gradients, inv->gradients.data(), inv->gradients.size() * 4, hipMemcpyHostToDevice));
     inv->tables_dirty = false;
+    ++inv->table_generation;
     return 0;
 }
 
@@ -696,9 +697,26 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     char *xy = inv->d_xy;
     void *params[] = {&a, &xy};
     {
-        int n = std::max(region_w, a.num_rows);
-        HIP_TRY(hipModuleLaunchKernel(f->f_pro, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
-        if (!f->ks.natives.empty() && run_natives(inv, a, s) != 0) return -1;
+        // The prologue's outputs (frame constants, coordinate tables) depend on the filter, the
+        // geometry, the user values / image table and -- only if its code reads them -- t and
+        // frame: while none of those changed since it last ran on these buffers, skip the launch
+        // (an animation of a filter whose constants do not involve t pays for it once).
+        HArgs key = a;
+        key.out = nullptr;
+        key.row_stride = key.output_bpp = key.floatmap = key.ppt = 0;
+        if (!f->ks.prologue_uses_time) { key.t = 0.0f; key.frame = 0; }
+        const bool fresh = f->ks.natives.empty() && inv->pro_filter == f && inv->pro_stream == (void *)s &&
+                           inv->pro_generation == inv->table_generation &&
+                           memcmp(&key, &inv->pro_args, sizeof key) == 0;
+        if (!fresh) {
+            int n = std::max(region_w, a.num_rows);
+            HIP_TRY(hipModuleLaunchKernel(f->f_pro, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
+            if (!f->ks.natives.empty() && run_natives(inv, a, s) != 0) return -1;
+            inv->pro_args = key;
+            inv->pro_filter = f;
+            inv->pro_stream = (void *)s;
+            inv->pro_generation = inv->table_generation;
+        }
     }
     int tiles_x = (region_w + f->ks.tile_w - 1) / f->ks.tile_w;
     // rows per work-item: enough workgroups must remain to fill 256 CUs several times over

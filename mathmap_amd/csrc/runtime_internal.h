@@ -61,6 +61,11 @@ struct mmhip_invocation {
     std::vector<unsigned long long> native_memo_gen;
     std::vector<std::pair<int, int>> native_rows;   // rows of native_maps[k] that are valid
     int native_row_margin = -1;                     // mmhip_set_native_row_margin
+    // the prologue kernel is skipped while nothing it reads has changed (mmhip_render)
+    mm::HArgs pro_args{};
+    const mmhip_filter *pro_filter = nullptr;
+    void *pro_stream = nullptr;
+    unsigned long long pro_generation = 0, table_generation = 1;
     unsigned long long input_generation = 1;
     char *d_xy = nullptr;
     int xy_cap = 0;
