@@ -142,6 +142,37 @@ def test_gauss_row_stripes_with_local_halo_equal_full_frame():
     assert np.array_equal(full.view(np.uint32), striped.view(np.uint32)), np.abs(full - striped).max()
 
 
+@pytest.mark.parametrize("intersample", [True, False])
+@pytest.mark.parametrize("ex,ey", [(0, 0), (1, 1), (2, 2), (3, 3), (1, 2), (3, 0), (0, 2), (2, 1)])
+def test_edge_behaviours_match_oracle(ex, ey, intersample):
+    """apply_edge_behaviour (builtins.c:40-119): COLOR with non-trivial edge colours, WRAP,
+    REFLECT, ROTATE in every mix of axes, sampling far outside the image, through the branch-free
+    hot fetch and the early-exit one (odd image sizes so the C `%` cases differ): bit-exact."""
+    w, h = 160, 96
+    img = W.synthetic_image(53, 37, seed=21)
+    src = "filter e (image in) in(xy * 2.7 + xy:[0.31, -0.23]) end"
+    colors = (0x20406080, 0xC0A01055)
+    for extra in ("", " * in(xy * 0.9)" * 0):
+        flt = mm.Filter(src, intersample=intersample, edge_x=ex, edge_y=ey)
+        inv = flt.invoke(w, h)
+        inv.set_image("in", img)
+        inv.set_edge_colors(*colors)
+        got = inv.render()
+        want = CpuFilter(flt.ir_json).render(w, h, images={"in": img}, intersample=intersample, edge=(ex, ey), edge_colors=colors)
+        assert np.array_equal(got, want), stats(got, want)
+    # the same through the one-pixel kernel shape (large bodies use the early-exit fetch)
+    import os
+    os.environ["MMHIP_SINGLE_PIXEL"] = "1"
+    try:
+        flt = mm.Filter(src + " ", intersample=intersample, edge_x=ex, edge_y=ey)
+        inv = flt.invoke(w, h)
+        inv.set_image("in", img)
+        inv.set_edge_colors(*colors)
+        assert np.array_equal(inv.render(), want)
+    finally:
+        del os.environ["MMHIP_SINGLE_PIXEL"]
+
+
 def test_nearest_sampling_matches_oracle():
     w, h = 300, 200
     img = W.synthetic_image(w, h, seed=5)
