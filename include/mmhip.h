@@ -125,6 +125,9 @@ int mmhip_sync(mmhip_invocation *inv);
    events on the launch stream; requires mmhip_enable_timing(inv, 1). */
 int mmhip_enable_timing(mmhip_invocation *inv, int on);
 double mmhip_last_kernel_ms(mmhip_invocation *inv);
+/* Durations of the pixel kernel of all timed launches since the last drain (oldest first, waits
+   for the last one): lets a caller queue many launches without a synchronisation per launch. */
+int mmhip_drain_kernel_ms(mmhip_invocation *inv, double *out_ms, int cap);
 
 /* device memory helpers for callers without their own allocator */
 void *mmhip_device_alloc(size_t bytes);

@@ -224,6 +224,14 @@ class Invocation:
     def last_kernel_ms(self):
         return lib().mmhip_last_kernel_ms(self._h)
 
+    def drain_kernel_ms(self, cap=4096):
+        """Pixel-kernel durations (ms) of every timed launch since the last drain, oldest first."""
+        buf = (C.c_double * cap)()
+        n = lib().mmhip_drain_kernel_ms(self._h, buf, cap)
+        if n < 0:
+            raise MathMapError(_err())
+        return [buf[i] for i in range(n)]
+
     def render(self, t=0.0, frame=0):
         """Renders the whole frame and returns it as a uint8 [H,W,4] array (RGBA)."""
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)

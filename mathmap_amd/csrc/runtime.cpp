@@ -338,8 +338,10 @@ void mmhip_invocation_free(mmhip_invocation *inv) {
     if (inv->d_ytab) (void)hipFree(inv->d_ytab);
     if (inv->d_curves) (void)hipFree(inv->d_curves);
     if (inv->d_gradients) (void)hipFree(inv->d_gradients);
-    if (inv->ev0) (void)hipEventDestroy(inv->ev0);
-    if (inv->ev1) (void)hipEventDestroy(inv->ev1);
+    for (auto &p : inv->ev_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
     if (inv->stream) (void)hipStreamDestroy(inv->stream);
     delete inv;
 }
@@ -486,11 +488,39 @@ int mmhip_set_sampling_offset(mmhip_invocation *inv, float ox, float oy) {
 
 int mmhip_enable_timing(mmhip_invocation *inv, int on) {
     inv->timing = on != 0;
-    if (on && !inv->ev0) {
-        HIP_TRY(hipEventCreate(&inv->ev0));
-        HIP_TRY(hipEventCreate(&inv->ev1));
-    }
     return 0;
+}
+
+// The next event pair for a timed launch (grown on demand, wraps after 4096 pending launches).
+static int next_event_pair(mmhip_invocation *inv) {
+    if (inv->ev_used == inv->ev_pool.size()) {
+        if (inv->ev_pool.size() >= 4096) inv->ev_used = 0;
+        else {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            inv->ev_pool.push_back({a, b});
+        }
+    }
+    inv->ev0 = inv->ev_pool[inv->ev_used].first;
+    inv->ev1 = inv->ev_pool[inv->ev_used].second;
+    ++inv->ev_used;
+    return 0;
+}
+
+// Durations (ms) of the pixel kernel of every timed launch since the last drain, oldest first;
+// waits for the last of them.  Returns how many were written (at most `cap`).
+int mmhip_drain_kernel_ms(mmhip_invocation *inv, double *out_ms, int cap) {
+    int n = 0;
+    if (inv->ev_used > 0 && hipEventSynchronize(inv->ev_pool[inv->ev_used - 1].second) != hipSuccess) return fail("event sync failed");
+    for (size_t i = 0; i < inv->ev_used && n < cap; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, inv->ev_pool[i].first, inv->ev_pool[i].second) != hipSuccess) return fail("event elapsed failed");
+        out_ms[n++] = ms;
+    }
+    inv->ev_used = 0;
+    inv->ev_valid = false;
+    return n;
 }
 
 double mmhip_last_kernel_ms(mmhip_invocation *inv) {
@@ -731,7 +761,10 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     int tiles_y = (a.num_rows + f->ks.tile_h * a.ppt - 1) / (f->ks.tile_h * a.ppt);
     long nwg = (long)tiles_x * tiles_y;
     if (nwg > 0x7fffffffL) return fail("region too large for one launch");
-    if (inv->timing) HIP_TRY(hipEventRecord(inv->ev0, s));
+    if (inv->timing) {
+        if (next_event_pair(inv) != 0) return -1;
+        HIP_TRY(hipEventRecord(inv->ev0, s));
+    }
     HIP_TRY(hipModuleLaunchKernel(f->f_pix, (unsigned)nwg, 1, 1, 256, 1, 1, 0, s, params, nullptr));
     if (inv->timing) {
         HIP_TRY(hipEventRecord(inv->ev1, s));

@@ -75,8 +75,12 @@ struct mmhip_invocation {
     uint32_t edge_color_x = 0, edge_color_y = 0;
     float sampling_offset_x = 0.f, sampling_offset_y = 0.f;
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // the pair of the most recent launch (aliases into ev_pool)
     bool ev_valid = false;
+    // one event pair per timed launch, so a caller can queue many launches and read all durations
+    // afterwards without a synchronisation per launch (mmhip_drain_kernel_ms)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
     mm::NativeWorkspace ws;
 };
 
