@@ -122,9 +122,12 @@ struct LineArgs { int n; int lines; };
 
 __device__ __forceinline__ double iir_step(double s0, double s1, double s2, double s3, double s4, double v1, double v2,
                                            double v3, double v4, const double *n, const double *d) {
-    // gauss.c:181-185 with terms = 4: acc starts at 0 and adds (n[i]*s[k-i] - d[i]*v[k-i]) for i = 0..4
+    // gauss.c:181-185 with terms = 4: acc starts at 0 and adds (n[i]*s[k-i] - d[i]*v[k-i]) for i = 0..4.
+    // i = 0 reads d[0]*acc with acc = +0 and d[0] = 0.0 (find_iir_constants sets d_p[0] = d_m[0] = 0):
+    // that product is +0 and x - (+0) is x for every x (signed zeros, NaN included), so the term is
+    // n[0]*s0; the addition to the +0 accumulator stays (it turns a -0 product into +0).
     double acc = 0.0;
-    acc += n[0] * s0 - d[0] * acc;
+    acc += n[0] * s0;
     acc += n[1] * s1 - d[1] * v1;
     acc += n[2] * s2 - d[2] * v2;
     acc += n[3] * s3 - d[3] * v3;
@@ -137,7 +140,7 @@ __device__ __forceinline__ double iir_edge_step(int j, double s0, double s1, dou
                                                 double v3, const double *n, const double *d, const double *bd,
                                                 float initial) {
     double acc = 0.0;
-    acc += n[0] * s0 - d[0] * acc;
+    acc += n[0] * s0;        // d[0] = 0: see iir_step
     if (j >= 1) acc += n[1] * s1 - d[1] * v1; else acc += (n[1] - bd[1]) * initial;
     if (j >= 2) acc += n[2] * s2 - d[2] * v2; else acc += (n[2] - bd[2]) * initial;
     if (j >= 3) acc += n[3] * s3 - d[3] * v3; else acc += (n[3] - bd[3]) * initial;
