@@ -10,6 +10,7 @@
 #include <cassert>
 #include <cmath>
 #include <map>
+#include <set>
 
 #include "front.h"
 #include "gen.h"
@@ -71,6 +72,12 @@ class Lowerer {
     void gen_closure(AstNode *n, CompVar **dest, bool alloced);
     bool single_const(AstNode *n, int *iv);
     bool const_value(const Value *v, Primary *out, int depth = 0);
+    // tree vectors (dynamic tuple subscripts), lowered to element variables + select chains
+    std::set<const AstNode *> vector_selects_;
+    void find_vector_variables(AstNode *n);
+    CompVar *clamped_index(AstNode *sub, int len);
+    CompVar *dynamic_read(const std::vector<CompVar *> &elems, CompVar *idx);
+    void to_float(CompVar *dst, CompVar *src) { g_.assign_op(dst, "INT2FLOAT", {g_.P(src)}); }
     ImageChain resolve_image(Value *v);
     void alloc_var(Variable *v);
     void reset_vars(FilterVars *fv);
@@ -174,7 +181,7 @@ void Lowerer::alloc_var(Variable *v) {
     for (int i = 0; i < v->type.len; ++i)
         if (!v->compvar[i]) {
             bool is_image = v->type.tag == m_.tags.image && v->type.len == 1;
-            v->compvar[i] = code_.new_var(is_image ? Ty::Image : Ty::Int, v->name, i);
+            v->compvar[i] = code_.new_var(is_image ? Ty::Image : v->is_vector ? Ty::Float : Ty::Int, v->name, i);
         }
 }
 
@@ -205,6 +212,7 @@ void Lowerer::gen_filter(Filter *f, const std::vector<Primary> *args, CompVar *r
     reset_vars(env.vars);
     env_ = &env;
 
+    find_vector_variables(f->body);
     gen_limit_bindings();
     if (args) {
         int n = (int)args->size();
@@ -277,6 +285,57 @@ bool Lowerer::single_const(AstNode *n, int *iv) {
             return false;
         default: return false;
     }
+}
+
+// compiler.c:2521-2600 (find_all_vector_variables): a variable that is subscripted with a
+// non-constant index anywhere in the filter is a "tree vector" everywhere in it.  The reference
+// stores such a variable as a persistent tree of floats (tree_vectors.c) with clamped indices; the
+// tuple length is static, so here it stays `len` float element variables: a dynamic read is a
+// chain of conditional copies, a dynamic write a chain of conditional stores -- same values
+// (elements are converted to float on every store, like the C float array; reads are floats).
+void Lowerer::find_vector_variables(AstNode *n) {
+    if (!n) return;
+    for (AstNode *k : n->kids) find_vector_variables(k);
+    for (AstNode *k : n->subs) find_vector_variables(k);
+    int dummy;
+    if (n->kind == AstNode::Select) {
+        for (AstNode *sub : n->subs)
+            if (!single_const(sub, &dummy)) {
+                vector_selects_.insert(n);
+                if (n->kids[0]->kind == AstNode::Var) n->kids[0]->var->is_vector = true;
+            }
+    } else if (n->kind == AstNode::SubAssign) {
+        for (AstNode *sub : n->subs)
+            if (!single_const(sub, &dummy)) n->var->is_vector = true;
+    }
+}
+
+// TREE_VECTOR_NTH / SET_TREE_VECTOR_NTH take the index as a C int and clamp it (tree_vectors.c:96-99)
+CompVar *Lowerer::clamped_index(AstNode *sub, int len) {
+    std::vector<CompVar *> sv = gen_new(sub);
+    CompVar *idx = g_.temp();
+    g_.assign_op(idx, "FLOAT2INT", {g_.P(sv[0])});
+    g_.start_if(Rhs::O(g_.op("LESS", 2), {g_.P(idx), Primary::I(0)}));
+    g_.assign(idx, Rhs::I(0));
+    g_.switch_branch();
+    g_.end_if();
+    g_.start_if(Rhs::O(g_.op("LESS", 2), {Primary::I(len - 1), g_.P(idx)}));
+    g_.assign(idx, Rhs::I(len - 1));
+    g_.switch_branch();
+    g_.end_if();
+    return idx;
+}
+
+CompVar *Lowerer::dynamic_read(const std::vector<CompVar *> &elems, CompVar *idx) {
+    CompVar *r = g_.temp(Ty::Float);
+    g_.copy(r, elems[0]);
+    for (size_t k = 1; k < elems.size(); ++k) {
+        g_.start_if(Rhs::O(g_.op("EQ", 2), {g_.P(idx), Primary::I((int)k)}));
+        g_.copy(r, elems[k]);
+        g_.switch_branch();
+        g_.end_if();
+    }
+    return r;
 }
 
 // The literal an SSA value is known to hold while lowering (copies and foldable ops of
@@ -419,10 +478,22 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
         case AstNode::Select: {
             std::vector<CompVar *> temps = gen_new(n->kids[0]);
             int len = n->kids[0]->result.len;
+            if (vector_selects_.count(n) && !(n->kids[0]->kind == AstNode::Var && n->kids[0]->var->is_vector)) {
+                // dynamic subscript of an expression: gen_tree_vector builds a float vector of its value
+                for (CompVar *&tv : temps) {
+                    CompVar *f = g_.temp(Ty::Float);
+                    to_float(f, tv);
+                    tv = f;
+                }
+            }
             for (size_t i = 0; i < n->subs.size(); ++i) {
                 int sub;
-                if (!single_const(n->subs[i], &sub))
-                    throw CompileError("dynamic tuple subscripts (tree vectors) are not supported yet", n->pos);
+                if (!single_const(n->subs[i], &sub)) {
+                    CompVar *r = dynamic_read(temps, clamped_index(n->subs[i], len));
+                    if (!alloced) dest[i] = r;
+                    else g_.copy(dest[i], r);
+                    continue;
+                }
                 if (sub < 0) sub = 0;
                 if (sub >= len) sub = len - 1;
                 if (!alloced) dest[i] = temps[sub];
@@ -446,6 +517,15 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
         }
         case AstNode::Assign:
             alloc_var(n->var);
+            if (n->var->is_vector) {      // compiler.c:1995-1999: the value, then a float vector built from it
+                std::vector<CompVar *> vals = gen_new(n->kids[0]);
+                for (int i = 0; i < n->result.len; ++i) {
+                    to_float(n->var->compvar[i], vals[i]);
+                    if (alloced) g_.copy(dest[i], vals[i]);
+                    else dest[i] = vals[i];
+                }
+                break;
+            }
             gen(n->kids[0], n->var->compvar.data(), true);
             for (int i = 0; i < n->result.len; ++i) {
                 if (alloced) g_.copy(dest[i], n->var->compvar[i]);
@@ -458,8 +538,22 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
             int len = n->var->type.len;
             for (size_t i = 0; i < n->subs.size(); ++i) {
                 int sub;
+                if (n->var->is_vector) {      // SET_TREE_VECTOR_NTH, also for constant subscripts (compiler.c:2027-2038)
+                    CompVar *idx = clamped_index(n->subs[i], len);
+                    CompVar *fv = g_.temp(Ty::Float);
+                    to_float(fv, temps[i]);
+                    for (int k = 0; k < len; ++k) {
+                        g_.start_if(Rhs::O(g_.op("EQ", 2), {g_.P(idx), Primary::I(k)}));
+                        g_.copy(n->var->compvar[k], fv);
+                        g_.switch_branch();
+                        g_.end_if();
+                    }
+                    if (alloced) g_.copy(dest[i], temps[i]);
+                    else dest[i] = temps[i];
+                    continue;
+                }
                 if (!single_const(n->subs[i], &sub))
-                    throw CompileError("dynamic tuple subscripts (tree vectors) are not supported yet", n->pos);
+                    throw CompileError("internal: dynamic subscript on a variable that was not marked as a vector", n->pos);
                 if (sub < 0) sub = 0;
                 if (sub >= len) sub = len - 1;
                 g_.copy(n->var->compvar[sub], temps[i]);

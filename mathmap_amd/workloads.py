@@ -393,6 +393,19 @@ def test_gradient():
     return ((i >> 2) << 24) | (((1023 - i) >> 2) << 16) | np.uint32(0x40 << 8) | np.uint32(0xFF)
 
 
+# dynamic tuple subscripts ("tree vectors", compiler.c:1840-2040, tree_vectors.c): reads and writes
+# with run-time indices (clamped), on a variable and on an expression value
+TREE_VECTOR = """
+filter tv (int k: 0-8 (2))
+  v = rgba:[x, y, x*y, 1];
+  i = floor((x + 1) * 2.5) - 1;
+  w = v[i];
+  v[i + 1] = 0.25;
+  u = ([0.1, 0.5, 0.9])[floor(abs(y) * 40)];
+  rgba:[w, v[2], u, v[k]]
+end
+"""
+
 ALL = {
     "ident": IDENT,
     "mandelbrot": MANDELBROT,
@@ -408,6 +421,7 @@ ALL = {
     "convolve": CONVOLVE,
     "half_convolve": HALF_CONVOLVE,
     "curve_gradient": CURVE_GRADIENT,
+    "tree_vector": TREE_VECTOR,
 }
 
 

@@ -159,6 +159,26 @@ def test_every_reference_example_compiles_for_gfx950():
     assert not bad, bad
 
 
+def test_dynamic_subscripts_follow_tree_vector_semantics():
+    """v[i] / v[i] = x with run-time i (the reference's tree vectors): indices are truncated to int and
+    clamped to the tuple, elements are floats, a write replaces one element.  Expected values
+    computed independently with numpy."""
+    w, h = 64, 8
+    out = CpuFilter(mm.Filter(W.TREE_VECTOR).ir_json).render(w, h, floatmap=True)
+    col = np.arange(w, dtype=np.float64)
+    x = ((col - (w - 1) / 2.0) / ((w - 1) / 2.0)).astype(np.float32)                        # X = 1
+    for row in range(h):
+        y = np.float32(np.float32((-(row) + (h - 1) / 2.0) / ((h - 1) / 2.0)) * np.float32(h / w))   # Y = h / max(w, h)
+        v = np.stack([x, np.full(w, y, np.float32), x * y, np.ones(w, np.float32)], axis=1)
+        i = np.floor((x + np.float32(1)) * np.float32(2.5)).astype(int) - 1
+        ic = np.clip(i, 0, 3)
+        wv = v[np.arange(w), ic]
+        v[np.arange(w), np.clip(i + 1, 0, 3)] = 0.25
+        u = np.array([0.1, 0.5, 0.9], np.float32)[min(int(np.floor(abs(y) * np.float32(40))), 2)]
+        want = np.stack([wv, v[:, 2], np.full(w, u, np.float32), v[:, 2]], axis=1)
+        assert np.array_equal(out[row], want), row
+
+
 # ---- host logic ----------------------------------------------------------------------------
 def test_parse_errors_are_reported():
     for bad, msg in [("filter f () [1,2] end", "rgba:4"), ("filter f () q end", "Undefined variable"),

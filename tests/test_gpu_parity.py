@@ -536,6 +536,28 @@ def test_rand_is_deterministic_and_stripe_invariant():
     assert abs(np.corrcoef(v[:, :-1].ravel(), v[:, 1:].ravel())[0, 1]) < 0.02
 
 
+def test_dynamic_subscripts_on_gpu():
+    """Tree vectors (dynamic tuple subscripts) are lowered to element variables and select chains:
+    HIP == oracle bit for bit, for several values of the run-time index user value."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = 192, 96
+    flt = mm.Filter(W.TREE_VECTOR)
+    for k in (0, 2, 3, 7):
+        inv = flt.invoke(w, h)
+        inv.set("k", k)
+        dev = lib().mmhip_device_alloc(w * h * 16)
+        try:
+            inv.render_rows(dev, 0, h, floatmap=True)
+            inv.sync()
+            got = np.empty((h, w, 4), np.float32)
+            assert lib().mmhip_copy_to_host(got.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * 16) == 0
+        finally:
+            lib().mmhip_device_free(C.c_void_p(dev))
+        want = CpuFilter(flt.ir_json).render(w, h, uservals={"k": k}, floatmap=True)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), k
+
+
 def test_curve_and_gradient_user_values(marlene):
     """Curve / gradient LUT user values (APPLY_CURVE / APPLY_GRADIENT, opmacros.h:192-194): default
     ramps and explicitly set tables, HIP vs oracle, bit-exact."""
