@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="frame edge in pixels (default 8192; 16384 for gauss)")
     ap.add_argument("--tile-w", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="frames", choices=["frames", "stripes"],
+                    help="multi-GPU decomposition: one whole frame per rank and step (weak scaling, default) or every "
+                         "frame row-striped across the ranks (strong scaling; BASELINE config 5)")
     ap.add_argument("--no-generic", action="store_true", help="skip the generic-kernel comparison (for profiling runs)")
     ap.add_argument("--specialize", type=int, default=1,
                     help="1 = user-value specialising JIT (default), 0 = generic kernel reading user values at run time")
@@ -79,14 +82,21 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     inv.enable_timing(True)
 
+    from mathmap_amd.striping import stripe_rows
+    stripes = args.mode == "stripes" and world > 1
+    row_lo, row_hi = stripe_rows(h, rank, world) if stripes else (0, h)
+    if stripes:
+        inv.set_native_row_margin(0)          # a blur stripe computes its own rows + halo locally
+
     def step(i):
-        # one animation frame per rank and step: frame index i*world+rank, t = frame/120
-        fr = i * world + rank
+        # frames mode: one animation frame per rank and step (frame index i*world+rank, t = frame/120);
+        # stripes mode: every rank renders its row stripe of frame i
+        fr = i if stripes else i * world + rank
         if args.workload == "gauss":
             # a new input generation per frame, otherwise the native-filter memo
             # (native-filters/cache.c semantics) would reuse the blurred map
             inv.set_image_device("in", dev_img.data_ptr(), w, h)
-        inv.render_rows(out.data_ptr(), 0, h, t=(fr % 120) / 120.0, frame=0, stream=stream)
+        inv.render_rows(out.data_ptr() + row_lo * w * 4, row_lo, row_hi, t=(fr % 120) / 120.0, frame=0, stream=stream)
 
     for i in range(args.warmup):
         step(i)
@@ -109,7 +119,7 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        mpix = w * h * args.steps * world / 1e6
+        mpix = w * h * args.steps * (1 if stripes else world) / 1e6
         value = mpix / elapsed
         kernel_ms = inv.drain_kernel_ms()        # HIP events recorded on the launch stream around every launch
         k_ms = float(np.mean(kernel_ms))
@@ -131,11 +141,13 @@ def main():
         res = {
             "metric": "Mpixels/sec (%s @%dx%d)" % (args.workload, w, h),
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if stripes else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "examples/Render/Mandelbrot 8192x8192, defaults (num_iterations=32), RGBA8 out"
                        if args.workload == "mandelbrot" else "%s %dx%d" % (args.workload, w, h),
-                       "frames_per_step_per_gpu": 1, "parallelism": "frames x %d (no data-path collective)" % world,
+                       "frames_per_step_per_gpu": (1.0 / world) if stripes else 1,
+                       "parallelism": ("row stripes x %d of one frame (no data-path collective)" if stripes
+                                       else "frames x %d (no data-path collective)") % world,
                        "jit_seconds": round(jit_s, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
