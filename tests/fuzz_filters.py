@@ -98,6 +98,42 @@ class Gen:
             self.lines.append("if %s then %s = %s else %s = %s end;" % (self.cond(2), v, self.scalar(2), v, self.scalar(2)))
 
 
+def make_filter_ex(seed):
+    """Richer variant: filter flags (pixel / stretched), a second image of another size, complex
+    arithmetic, a helper filter applied as a closure, tuple arithmetic on fetched colours.  Returns
+    (source, image names, render options)."""
+    g = Gen(seed ^ 0x5eed)
+    r = g.r
+    g.uses_image_ok = True
+    flag = r.choice(["", "", "pixel ", "stretched "])
+    for _ in range(r.randint(1, 4)):
+        g.statement()
+    scale = "W" if flag == "pixel " else "1"
+    kind = r.random()
+    images = ["in"]
+    helper = ""
+    if kind < 0.3:
+        images.append("in2")
+        result = "in(xy) * %s + in2(xy * %s + xy:[%s, %s] * %s * 0.05) * (1 - %s)" % (
+            "0.5", r.choice(["0.5", "1", "1.5"]), g.scalar(2), g.scalar(2), scale, "0.5")
+    elif kind < 0.55:
+        z = "ri:[%s, %s]" % (g.scalar(2), g.scalar(2))
+        op = r.choice(["%s * %s", "%s + %s", "exp(%s * 0.3) + %s", "sin(%s) * %s", "sqrt(%s) - %s", "%s / (%s + ri:[2, 0.5])"])
+        zz = op % (z, "ri:[%s, 0.5]" % g.scalar(1))
+        g.lines.append("zc = %s;" % zz)
+        result = "in(xy + xy:[zc[0], zc[1]] * %s * 0.02)" % scale
+    elif kind < 0.8:
+        helper = "filter hlp%d (image im, float s: 0-2 (1))\n  im(xy * s) * 0.5 + grayColor(%s) * 0.5\nend\n\n" % (seed, "abs(sin(x * 3 + s))")
+        result = "hlp%d(in, %s, xy + xy:[%s, 0] * %s * 0.03)" % (seed, r.choice(["0.7", "1", "m"]), g.scalar(2), scale)
+    else:
+        result = "lerp(%s, in(xy), rgba:[%s, %s, 0.5, 1])" % ("0.5", g.scalar(2), g.scalar(2))
+    params = ["image in"] + (["image in2"] if "in2" in images else []) + ["int k: 0-8 (3)", "float m: 0-2 (0.7)"]
+    src = "%s%sfilter fx%d (%s)\n  %s\n  %s\nend\n" % (helper, flag, seed, ", ".join(params), "\n  ".join(g.lines), result)
+    src = src.replace("\\n", "\n")
+    opts = dict(intersample=r.random() < 0.7, edge_x=r.choice([0, 0, 1, 2, 3]), edge_y=r.choice([0, 0, 1, 2, 3]))
+    return src, images, opts
+
+
 def make_filter(seed, with_image=True):
     g = Gen(seed)
     g.uses_image_ok = with_image

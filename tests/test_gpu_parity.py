@@ -685,6 +685,33 @@ def test_random_filters_hip_vs_oracle_and_specialised_vs_generic(seed):
     assert mx <= 1 or n1 < 0.01 * want.size, "seed %d: max %d, %d differ, %d by more than 1\n%s" % (seed, mx, nd, n1, src)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_filters_with_closures_complex_ops_and_options(seed):
+    """The richer generator (filter flags, a second image, complex arithmetic, a helper filter
+    applied as a closure, random intersampling / edge behaviours): HIP vs oracle, specialised vs
+    generic."""
+    from tests.fuzz_filters import make_filter_ex
+    src, names, opts = make_filter_ex(seed)
+    w, h = 96, 64
+    imgs = {"in": W.synthetic_image(w, h, seed=1), "in2": W.synthetic_image(50, 70, seed=2)}
+    uv = {"k": seed % 7, "m": 0.3 + (seed % 5) * 0.4}
+    outs = []
+    for spec in (False, True):
+        flt = mm.Filter(src, specialize=spec, **opts)
+        inv = flt.invoke(w, h)
+        for k, v in uv.items():
+            inv.set(k, v)
+        for n in names:
+            inv.set_image(n, imgs[n])
+        outs.append(inv.render(t=0.4))
+    assert np.array_equal(outs[0], outs[1]), "specialised kernel differs from the generic one"
+    want = CpuFilter(mm.Filter(src, **opts).ir_json).render(
+        w, h, uservals=uv, images={n: imgs[n] for n in names}, t=0.4, intersample=opts["intersample"],
+        edge=(opts["edge_x"], opts["edge_y"]))
+    mx, nd, n1 = stats(outs[0], want)
+    assert mx <= 1 or n1 < 0.01 * want.size, "seed %d: max %d, %d differ, %d by more than 1\n%s" % (seed, mx, nd, n1, src)
+
+
 def _example_manifest():
     import json
     import os
