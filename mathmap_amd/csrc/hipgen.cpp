@@ -192,6 +192,15 @@ struct Generator {
                     preloaded_desc.count(r.args[2].value))
                     return "mm_orig_val_d(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " + prim(r.args[2], sl) +
                            ", " + prim(r.args[3], sl) + ", " + vname(r.args[2].value) + "_desc)";
+                // x / c with c = +-2^k: x * (1/c) is the same correctly rounded value (scaling by a power of two
+                // is exact or rounds identically, subnormals and overflow included), one multiply instead of
+                // the ~10-instruction IEEE division sequence
+                if (opt.fast_math_exact && !strcmp(cn, "DIV") && r.args.size() == 2 && r.args[1].kind == Primary::FloatConst) {
+                    int ex = 0;
+                    const float c = r.args[1].f;
+                    if (std::isfinite(c) && c != 0.0f && std::fabs(std::frexp(c, &ex)) == 0.5f && ex > -100 && ex < 100)
+                        return "((float)(" + prim(r.args[0], sl) + ") * " + float_literal(1.0f / c) + "f)";
+                }
                 std::string name = cn;
                 if (const char *lm = libm_name(cn)) name = lm;
                 // exact f32 fast path: (float)sqrt((double)f) == sqrtf(f), correctly rounded

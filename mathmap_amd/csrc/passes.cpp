@@ -9,6 +9,7 @@
 //    depend on the pixel position are computed once per frame by a one-lane
 //    prologue kernel and reach the pixel kernel through a small constant buffer
 //    (scalar loads), everything else runs per work-item.
+#include <cctype>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -273,7 +274,70 @@ bool internal_is_frame_const(const std::string &n) { return n != "x" && n != "y"
 // flow, or through control flow) as not hoistable; the rest is `hoisted`.  Then
 // statements are assigned to the prologue slice, the pixel slice, or both
 // (control statements whose bodies contain work of both kinds).
+static void analyze_frame_constants_once(FilterCode &code);
+
+// Speculative hoisting: a pure library call (cexpf, sin, pow ...) whose operands are literals or
+// frame constants is itself a frame constant even when it sits inside pixel-dependent control
+// flow -- Droste evaluates cexpf(0 + 2 pi i) in a branch most pixels take.  Pure and total, so
+// executing it unconditionally is safe; moved in front of its outermost enclosing statement it
+// lands in the prologue slice (once per frame).  Only calls (and the COMPLEX(...) constructors
+// feeding them) are moved: hoisting plain arithmetic would just turn registers into transfers.
+static bool hoist_speculative(FilterCode &code) {
+    bool moved_any = false;
+    for (size_t ti = 0; ti < code.body.size(); ++ti) {
+        Stmt *top = code.body[ti];
+        if (top->kind != Stmt::If && top->kind != Stmt::While) continue;
+        std::set<const Stmt *> inside;
+        std::function<void(Block &)> collect = [&](Block &b) {
+            for (Stmt *s : b) {
+                inside.insert(s);
+                if (s->kind == Stmt::If) { collect(s->then_); collect(s->else_); collect(s->phis); }
+                if (s->kind == Stmt::While) { collect(s->phis); collect(s->body); }
+            }
+        };
+        collect(top->then_); collect(top->else_); collect(top->phis); collect(top->body);
+        std::vector<Stmt *> moved;
+        std::set<const Value *> moved_vals;
+        std::function<void(Block &)> scan = [&](Block &b) {
+            for (size_t i = 0; i < b.size(); ++i) {
+                Stmt *s = b[i];
+                if (s->kind == Stmt::If) { scan(s->then_); scan(s->else_); continue; }
+                if (s->kind == Stmt::While) { scan(s->body); continue; }
+                if (s->kind != Stmt::Assign || s->rhs.kind != Rhs::Op || !s->rhs.op->pure || s->lhs->hoisted) continue;
+                const char *n = s->rhs.op->cname;
+                if (!(std::islower((unsigned char)n[0]) || !strcmp(n, "COMPLEX"))) continue;
+                bool ok = true;
+                for (const Primary &p : s->rhs.args) {
+                    if (p.kind != Primary::Val) continue;
+                    if (moved_vals.count(p.value)) continue;
+                    if (p.value->index < 0 || !p.value->hoisted || inside.count(p.value->def)) { ok = false; break; }
+                }
+                if (!ok) continue;
+                b.erase(b.begin() + i);
+                --i;
+                moved.push_back(s);
+                moved_vals.insert(s->lhs);
+            }
+        };
+        scan(top->then_); scan(top->else_); scan(top->body);
+        // a COMPLEX(...) that no moved call uses goes back?  It is harmless at top level: it is a
+        // frame constant there and dead-code elimination removes it if unused
+        for (Stmt *s : moved) {
+            s->parent = top->parent;
+            code.body.insert(code.body.begin() + ti, s);
+            ++ti;
+            moved_any = true;
+        }
+    }
+    return moved_any;
+}
+
 void analyze_frame_constants(FilterCode &code) {
+    analyze_frame_constants_once(code);
+    if (hoist_speculative(code)) analyze_frame_constants_once(code);
+}
+
+static void analyze_frame_constants_once(FilterCode &code) {
     for (Value &v : code.values) v.hoisted = true;
     bool changed = true;
     auto prim_hoisted = [](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted; };
