@@ -476,9 +476,10 @@ mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_i
             imp.find_result();
             std::string err;
             if (!mmhip_filter_finalize(f, k, &err)) throw CompileError(err);
-            // user values arrive with every calc_lines call: specialise a kernel for a value set
-            // once it is seen a second time (bands of one frame, frames of an animation), not on
-            // every slider move of an interactive host (MATHMAP_HIP_SPECIALIZE=0 turns it off)
+            // user values arrive with every calc_lines call: specialise a kernel for a value set once it
+            // is rendered for a second frame (an animation over t), never for bands of one frame or
+            // for values that change with every render (slider moves, animated user values);
+            // MATHMAP_HIP_SPECIALIZE=0 turns it off
             const char *e = getenv("MATHMAP_HIP_SPECIALIZE");
             f->specialize = !(e && atoi(e) == 0);
             f->spec_min_uses = 2;

@@ -633,7 +633,7 @@ static mmhip_filter *compile_ir_specialized(const mmhip_filter *f, const std::ma
 // The kernel set to launch: the generic filter, or -- with options.specialize_uservals -- a
 // variant with the current scalar user values baked in as literals (built on first use per
 // value set, cached on the filter and on disk through the hiprtc cache).
-static mmhip_filter *active_filter(mmhip_invocation *inv) {
+static mmhip_filter *active_filter(mmhip_invocation *inv, int frame = 0, float t = 0.0f) {
     mmhip_filter *f = inv->f;
     if (!f->specialize || !f->ks.natives.empty() || (f->source.empty() && f->ir_json.empty())) return f;
     g_err.clear();
@@ -651,7 +651,19 @@ static mmhip_filter *active_filter(mmhip_invocation *inv) {
     if (it != f->spec_cache.end()) return it->second ? it->second : f;
     // a host that changes values on every render (interactive sliders) should not pay a JIT each
     // time: build the variant on the spec_min_uses-th render with the same values
-    if (!f->deferred && ++f->spec_uses[key] < f->spec_min_uses) return f;
+    // A "use" is a render of a new frame with these values: the bands of one frame count once, so a
+    // host that animates a user value (new values every frame, several calc_lines bands each) never
+    // triggers a JIT per frame; an animation over t with fixed values specialises at its 2nd frame.
+    if (!f->deferred && f->spec_min_uses > 1) {
+        if (f->spec_uses.size() > 1024) f->spec_uses.clear();
+        auto &u = f->spec_uses[key];
+        if (u.count == 0 || u.frame != frame || u.t != t) {
+            ++u.count;
+            u.frame = frame;
+            u.t = t;
+        }
+        if (u.count < f->spec_min_uses) return f;
+    }
     f->spec_uses.erase(key);
     mmhip_options o = f->opts;
     o.specialize_uservals = 0;
@@ -663,7 +675,7 @@ static mmhip_filter *active_filter(mmhip_invocation *inv) {
 
 int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
                  int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream) {
-    mmhip_filter *f = active_filter(inv);
+    mmhip_filter *f = active_filter(inv, frame, t);
     if (f->deferred) return fail(g_err.empty() ? f->deferred_reason : g_err);
     hipStream_t s = stream ? (hipStream_t)stream : inv->stream;
     if (bpp < 1 || bpp > 4) return fail("output_bpp must be 1..4");

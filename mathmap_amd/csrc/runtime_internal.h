@@ -33,7 +33,8 @@ struct mmhip_filter {
     mmhip_options opts{};
     bool specialize = false;
     std::map<std::string, mmhip_filter *> spec_cache;
-    std::map<std::string, int> spec_uses;     // renders seen per value set that has no variant yet
+    struct SpecUse { int count = 0; int frame = 0; float t = 0.0f; };
+    std::map<std::string, SpecUse> spec_uses; // frames seen per value set that has no variant yet
     int spec_min_uses = 1;                    // build the variant on this many-th render with one value set
     // a filter that only compiles with its scalar user values baked in (recursion whose depth
     // they control): no generic code/kernels, every render goes through spec_cache
