@@ -399,10 +399,16 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
         frame.frame_render_width = w;
         frame.frame_render_height = h;
         frame.current_frame = 0;
-        frame.current_t = t;
+        // MMHIP_SELFTEST_WARM_FRAMES=n: render n earlier frames (t - n/16 ... t - 1/16) first, like an
+        // animation; from its 2nd frame on the backend runs the user-value-specialised variant
+        int warm = 0;
+        if (const char *e = getenv("MMHIP_SELFTEST_WARM_FRAMES")) warm = atoi(e);
+        if (num_bands < 1) num_bands = 1;
+        for (int wf = warm; wf >= 0; --wf) {
+        std::fill(rows_finished.begin(), rows_finished.end(), 0);
+        frame.current_t = t - (float)wf / 16.0f;
         inv.mathfuncs.init_frame(&frame, closure);
         // call_invocation_parallel (mathmap_common.c:972-1006): contiguous row bands
-        if (num_bands < 1) num_bands = 1;
         for (int b = 0; b < num_bands; ++b) {
             int lo = h * b / num_bands, hi = h * (b + 1) / num_bands;
             mmabi_slice_t slice;
@@ -414,6 +420,7 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
             slice.region_height = hi - lo;
             inv.mathfuncs.init_slice(&slice, closure);
             inv.mathfuncs.calc_lines(&slice, closure, lo, hi, out_rgba + (size_t)lo * inv.row_stride, 0);
+        }
         }
         int finished = 0;
         for (int r = 0; r < h; ++r) finished += rows_finished[r];

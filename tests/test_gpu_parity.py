@@ -245,6 +245,34 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     assert np.array_equal(got, want)
 
 
+def test_reference_abi_tier_specialises_from_the_second_frame(marlene):
+    """calc_lines driven for three frames of an animation (fixed user values, t advancing): the first
+    frame runs the generic kernel, later ones the variant built from the imported IR; the last
+    frame must equal the standalone render at its t."""
+    import ctypes as C
+    import os
+    from mathmap_amd._lib import lib
+    w, h = 256, 256
+    for name in ("mandelbrot", "pond"):
+        src = W.ALL[name]
+        needs = "image in" in src
+        inv = mm.Filter(src).invoke(w, h)
+        if needs:
+            inv.set_image("in", marlene)
+        want = inv.render(t=0.5)
+        got = np.zeros((h, w, 4), np.uint8)
+        img = np.ascontiguousarray(marlene)
+        os.environ["MMHIP_SELFTEST_WARM_FRAMES"] = "2"
+        try:
+            rc = lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p) if needs else None,
+                                                    img.shape[1], img.shape[0], 3, w, h, 0.5, 2,
+                                                    got.ctypes.data_as(C.c_void_p))
+        finally:
+            del os.environ["MMHIP_SELFTEST_WARM_FRAMES"]
+        assert rc == 0, lib().mmhip_selftest_error().decode()
+        assert np.array_equal(got, want), name
+
+
 MATH_PROBE = """
 filter probe (float k: 0-100 (1))
   u = x * k; v = y * k;
