@@ -215,6 +215,9 @@ struct Generator {
                     else if (!strcmp(cn, "exp")) name = "mmf_exp_f32";
                     else if (!strcmp(cn, "log")) name = "mmf_log_f32";
                 }
+                if (opt.fast_math_exact && !strcmp(cn, "pow") && lhs && lhs->type == Ty::Float && r.args.size() == 2 &&
+                    r.args[0].type() == Ty::Float && r.args[1].type() == Ty::Float)
+                    name = "mmf_pow_f32";
                 if (opt.fast_math_exact && !strcmp(cn, "hypot") && r.args.size() == 2 && r.args[0].type() == Ty::Float &&
                     r.args[1].type() == Ty::Float) {
                     name = "mm_hypot_ff";
@@ -497,6 +500,7 @@ struct Generator {
                "#define MMF_FABSF(a) __builtin_fabsf((a))\n#define MMF_FABS(a) __builtin_fabs((a))\n"
                "#define MMF_SIN_SLOW(a) sin((a))\n#define MMF_COS_SLOW(a) cos((a))\n"
                "#define MMF_LDEXP(a, e) __builtin_ldexp((a), (e))\n#define MMF_EXP_SLOW(a) exp((a))\n#define MMF_LOG_SLOW(a) log((a))\n"
+               "#define MMF_POW_SLOW(a, b) pow((a), (b))\n"
             << device_fastmath_prelude() << "\n";
         out << device_prelude() << "\n";
         if (uses_noise(code.body)) {

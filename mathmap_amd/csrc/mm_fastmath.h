@@ -106,6 +106,7 @@ MMF_FN void mmf_sincos_d(double xd, double *sn, double *cs) {
 #define MMF_LDEXP(a, e) ldexp((a), (e))
 #define MMF_EXP_SLOW(a) exp((a))
 #define MMF_LOG_SLOW(a) log((a))
+#define MMF_POW_SLOW(a, b) pow((a), (b))
 #endif
 
 MMF_CONST_TABLE double mmf_exp_table[128] = MMF_EXP_TABLE;
@@ -169,6 +170,98 @@ MMF_FN float mmf_log_f32(float x) {
     // positive finite floats only (denormals included: they are normal doubles)
     if (!(x > 0.0f && x <= 3.40282346638528859812e38f)) return (float)MMF_LOG_SLOW((double)x);
     return (float)mmf_log_d((double)x);
+}
+
+// ---- pow of two float arguments --------------------------------------------------------------
+// (float)pow((double)x, (double)y) = exp(y log x) with log x carried as a double-double: for a
+// float x the reduced argument r = m*invc - 1 is exact (invc has 20 bits), the table and
+// e*ln2 are double-double, so log x is good to about 2^-68; the product with y keeps its
+// rounding residual and exp() takes the high part, the low part enters as a final (1 + pl).
+// Two arguments cannot be enumerated: tools/verify_fastmath.c compares 4e9 random and
+// structured pairs with glibc (profiles/r01_verify_fastmath.json records the count and the
+// mismatches, 0 so far) -- OCML's pow differs from glibc's result in ~0.1 % of float roundings.
+MMF_FN void mmf_log_dd(double xd, double *hi, double *lo) {
+    union { double d; unsigned long long u; } b;
+    b.d = xd;
+    int e = (int)((b.u >> 52) & 0x7ff) - 1023;
+    b.u = (b.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = b.d;
+    int i = (int)MMF_RINT((m - 1.0) * 128.0);
+    if (i == 128) {
+        m *= 0.5;
+        e += 1;
+        i = 0;
+    }
+    const double invc = mmf_log_table[3 * i], lch = mmf_log_table[3 * i + 1], lcl = mmf_log_table[3 * i + 2];
+    const double r = MMF_FMA(m, invc, -1.0);                 // exact for a float-valued m
+    double q = MMF_FMA(r, 1.0 / 9.0, -0.125);
+    q = MMF_FMA(r, q, 1.0 / 7.0);
+    q = MMF_FMA(r, q, -1.0 / 6.0);
+    q = MMF_FMA(r, q, 0.2);
+    q = MMF_FMA(r, q, -0.25);
+    q = MMF_FMA(r, q, 1.0 / 3.0);
+    q = MMF_FMA(r, q, -0.5);
+    const double ed = (double)e;
+    const double s = ed * MMF_LN2_HI;                         // exact
+    const double t1 = s + lch;
+    const double e1 = (s - t1) + lch;                         // Fast2Sum (|s| >= |lch| or s == 0)
+    const double t2 = t1 + r;                                 // TwoSum
+    const double bb = t2 - t1;
+    const double e2 = (t1 - (t2 - bb)) + (r - bb);
+    // tail: everything below t2 (the polynomial part is up to 2^-9 of t2, so renormalise)
+    const double tail = MMF_FMA(r * r, q, (e1 + e2) + MMF_FMA(ed, MMF_LN2_LO, lcl));
+    const double h = t2 + tail;
+    *hi = h;
+    *lo = (t2 - h) + tail;                                    // Fast2Sum: |t2| >= |tail|
+}
+
+MMF_FN float mmf_pow_f32(float x, float y) {
+    if (!(x > 0.0f && x <= 3.40282346638528859812e38f) || !(MMF_FABSF(y) <= 3.40282346638528859812e38f))
+        return (float)MMF_POW_SLOW((double)x, (double)y);
+    const double xd = (double)x, yd = (double)y;
+    // Integer exponents whose power is exactly representable (x^2 always is: 48 bits) must come
+    // out exact -- an exact result can sit on a float rounding tie (11^7 = 19487171 needs 25
+    // bits), where being one double ulp off changes the float.  Square-and-multiply with an fma
+    // residual per product proves exactness; anything inexact continues below.
+    if (yd == MMF_RINT(yd) && MMF_FABS(yd) <= 64.0) {
+        int n = (int)MMF_FABS(yd);
+        double base = xd, acc = 1.0;
+        int exact = 1;
+        while (n) {
+            if (n & 1) {
+                const double p = acc * base;
+                exact = exact && MMF_FMA(acc, base, -p) == 0.0;
+                acc = p;
+            }
+            n >>= 1;
+            if (n) {
+                const double p = base * base;
+                exact = exact && MMF_FMA(base, base, -p) == 0.0;
+                base = p;
+            }
+        }
+        if (exact && acc <= 1.7976931348623157e308 && acc >= 2.2250738585072014e-308) {
+            if (yd >= 0.0) return (float)acc;
+            const double inv = 1.0 / acc;          // exact iff acc is a power of two; else one rounding of an inexact value
+            if (MMF_FMA(inv, acc, -1.0) == 0.0) return (float)inv;
+        }
+    }
+    double lh, ll;
+    mmf_log_dd(xd, &lh, &ll);
+    const double ph = yd * lh;
+    if (!(MMF_FABS(ph) <= 700.0)) return (float)MMF_POW_SLOW(xd, yd);
+    const double pl = MMF_FMA(yd, lh, -ph) + yd * ll;
+    const double res = mmf_exp_d(ph);
+    const double r = MMF_FMA(res, pl, res);
+    // A result within a few double ulps of a float rounding tie or of an exact float (low 29
+    // mantissa bits near 0x10000000 or 0) is decided by the platform pow, which is exact on exact
+    // cases; this happens about once in 2^26 calls.
+    union { double d; unsigned long long u; } b;
+    b.d = r;
+    const unsigned low = (unsigned)(b.u & 0x1fffffffULL);
+    const unsigned d_tie = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;
+    if (d_tie <= 4u) return (float)MMF_POW_SLOW(xd, yd);
+    return (float)r;
 }
 
 // Double-in, double-out variants with the range tests, for the float-complex functions.

@@ -333,10 +333,11 @@ def test_fastmath_sin_cos_equal_glibc_sampled():
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-pthread", os.path.join(ROOT, "tools", "verify_fastmath.c"),
                     "-o", exe, "-lm"], check=True)
-    r = subprocess.run([exe, "97"], stdout=subprocess.PIPE, text=True)
+    r = subprocess.run([exe, "97", "2000000"], stdout=subprocess.PIPE, text=True)
     rep = json.loads(r.stdout)
     assert r.returncode == 0 and rep["sin_mismatches"] == 0 and rep["cos_mismatches"] == 0, rep
     assert rep["exp_mismatches"] == 0 and rep["log_mismatches"] == 0, rep
+    assert rep["pow_mismatches"] == 0 and rep["pow_random_pairs_checked"] > 15_000_000, rep     # pow: sampled, not enumerable
     assert rep["checked"] > 25_000_000 and rep["exp_checked"] > 20_000_000 and rep["log_checked"] > 20_000_000
 
 

