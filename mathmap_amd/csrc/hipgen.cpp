@@ -2,12 +2,21 @@
 //
 // Shape of the generated translation unit:
 //
-//   #define MM_INTERSAMPLE ...           (specialisation constants)
-//   <mm_device.h>                        (device runtime)
-//   extern "C" __global__ void mm_prologue(mm_args A, char *XY)      one lane: frame-constant
-//                                                                    values -> constant buffer,
-//                                                                    native-filter call records
-//   extern "C" __global__ void mm_pixels(mm_args A, const char *XY)  one work-item per output pixel
+//   #define MM_INTERSAMPLE / MM_EDGE_X / MM_TILE_W / MM_UNROLL ...   (compile-time options)
+//   <mm_fastmath.h + tables, mm_gslmath.h>                           (float-argument libm, GSL ops)
+//   <mm_device.h>  [<mm_noise_device.h> + gradient table]            (device runtime)
+//   extern "C" __global__ void mm_prologue(mm_args A, char *XY)      lane 0: frame-constant values ->
+//                                                                    constant buffer, native-filter call
+//                                                                    records; all lanes: x / y tables
+//   extern "C" __global__ void mm_pixels(mm_args A, const char *XY)  pixel kernel, one of two shapes:
+//       loop shape   : frame constants + image descriptors loaded once, then A.ppt rows per work-item,
+//                      MM_UNROLL pixels evaluated back to back (stores deferred), with a branch-free
+//                      "hot" copy of the loop when every fetch reads a bound drawable
+//       single shape : one pixel per work-item, lazy scalar loads (large bodies: no SGPR spills)
+//
+// Environment hooks for experiments (never needed for correct operation): MMHIP_UNROLL,
+// MMHIP_SINGLE_PIXEL, MMHIP_WAVES_PER_EU here; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE,
+// MMHIP_CACHE_DIR in runtime.cpp.
 //
 // Statement printing follows the reference's backends/cc.c:192-397 (one C variable
 // per SSA value, phi copies at the end of branches / loop bodies), so the arithmetic
