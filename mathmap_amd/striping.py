@@ -56,3 +56,35 @@ def gather_stripes(local_stripe, height, rank, world, group=None):
         lo, hi = stripe_rows(height, r, world)
         parts.append(bufs[r][: hi - lo])
     return torch.cat(parts, dim=0)
+
+
+def replicate_input(image, height, width, rank, world, src=0, group=None):
+    """Replicates the packed RGBA8 input image (a [H, W] int32/uint32 tensor on rank `src`) on every
+    rank as scatter + all-gather: the source sends each rank a different 1/world slice (one slice
+    per xGMI link instead of the whole image down a ring), then the slices are all-gathered.
+    xGMI is point to point, 7 links x ~153 GB/s per GPU: a 268 MB frame takes ~0.3 ms this way
+    against ~1.8 ms for a single-link broadcast.  Returns the full image on every rank
+    (RCCL on GPU tensors, gloo on CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return image
+    n = height * width
+    chunk = (n + world - 1) // world
+    device = image.device if rank == src else None
+    dtype = image.dtype if rank == src else None
+    meta = [device, dtype]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    device, dtype = (meta[0] if rank != src else image.device), meta[1]
+    if rank != src and device.type == "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+    mine = torch.empty(chunk, dtype=dtype, device=device)
+    if rank == src:
+        flat = torch.zeros(chunk * world, dtype=dtype, device=device)
+        flat[:n] = image.reshape(-1)
+        dist.scatter(mine, list(flat.view(world, chunk).unbind(0)), src=src, group=group)
+    else:
+        dist.scatter(mine, None, src=src, group=group)
+    parts = [torch.empty(chunk, dtype=dtype, device=device) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.cat(parts)[:n].view(height, width)

@@ -16,7 +16,7 @@ WORKER = textwrap.dedent("""
     import numpy as np, torch, torch.distributed as dist
     import mathmap_amd as mm
     from mathmap_amd import workloads as W
-    from mathmap_amd.striping import stripe_rows, gather_stripes
+    from mathmap_amd.striping import stripe_rows, gather_stripes, replicate_input
     from oracle.ccgen import CpuFilter
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -28,6 +28,12 @@ WORKER = textwrap.dedent("""
     out = gather_stripes(stripe, h, rank, world)
     if rank == 0:
         np.save(sys.argv[1], out.numpy())
+    # input replication (scatter + all-gather): every rank ends up with rank 0's image
+    ih, iw = 37, 53
+    src_img = torch.arange(ih * iw, dtype=torch.int32).view(ih, iw) * 2654435 if rank == 0 else None
+    got = replicate_input(src_img, ih, iw, rank, world)
+    want = torch.arange(ih * iw, dtype=torch.int32).view(ih, iw) * 2654435
+    assert torch.equal(got, want), "replicate_input mismatch on rank %%d" %% rank
     dist.barrier()
     dist.destroy_process_group()
 """) % ROOT
