@@ -31,7 +31,7 @@ struct NativeWorkspace {
 // those rows plus their halo; [0, render_h) asks for the whole map.
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
-                      std::string *err, int row_lo, int row_hi);
+                      std::string *err, int *row_lo, int *row_hi);   // in: rows wanted, out: rows filled
 
 // native_fft.hip: convolve / half_convolve / visualize_fft (native-filters/convolve.c)
 int fft_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images, int render_w,

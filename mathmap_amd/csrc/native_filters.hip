@@ -512,7 +512,10 @@ int gauss_rle(float *map, float *tmp, int w, int h, float hs, float vs, NativeWo
 }
 
 int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, int rw, int rh, float *out_map,
-                  NativeWorkspace &ws, hipStream_t s, std::string *err, int row_lo, int row_hi) {
+                  NativeWorkspace &ws, hipStream_t s, std::string *err, int *rows_lo, int *rows_hi) {
+    const int row_lo = *rows_lo, row_hi = *rows_hi;
+    *rows_lo = 0;             // paths that fill the whole map leave it so; the windowed IIR path narrows it
+    *rows_hi = rh;
     const HImage &img = rec.args[0].img;
     float hdev = rec.args[1].f, vdev = rec.args[2].f;
     if (img.idx < 0 || img.idx >= (int)images.size()) { *err = "gaussian_blur: input is not a bitmap image"; return -1; }
@@ -595,6 +598,8 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         const int halo = (int)ceil(22.7 * (double)vs) + 2;
         y0 = std::max(0, row_lo - halo);
         y1 = std::min(h, row_hi + halo);
+        *rows_lo = std::max(0, row_lo);        // valid: the rows asked for (the halo rows are scratch)
+        *rows_hi = std::min(h, row_hi);
         if (y1 <= y0) return 0;
     }
     const int hn = y1 - y0;
@@ -678,9 +683,11 @@ void launch_supersample_combine(const unsigned char *longs, const unsigned char 
 
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
-                      std::string *err, int row_lo, int row_hi) {
+                      std::string *err, int *row_lo, int *row_hi) {
     if (func == "native_filter_gaussian_blur")
         return gaussian_blur(rec, images, render_w, render_h, out_map, ws, stream, err, row_lo, row_hi);
+    *row_lo = 0;              // every other native filter produces the whole map
+    *row_hi = render_h;
     if (func == "RENDER") {   // render_image (builtins.c:267-346), drawable / float-map branches
         const HImage &img = rec.args[0].img;
         if (img.idx < 0 || img.idx >= (int)images.size()) { *err = "render(): rendering a filter closure is not supported by the HIP backend yet"; return -1; }

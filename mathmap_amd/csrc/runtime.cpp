@@ -571,8 +571,9 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
         size_t bytes = (size_t)a.render_width * a.render_height * 16;
         if (!inv->native_maps[k]) HIP_TRY(hipMalloc(&inv->native_maps[k], bytes));
         std::string err;
+        int got_lo = want_lo, got_hi = want_hi;
         int rc = run_native_filter(f->ks.natives[k].func, rec, inv->images, a.render_width, a.render_height,
-                                   (float *)inv->native_maps[k], inv->ws, s, &err, want_lo, want_hi);
+                                   (float *)inv->native_maps[k], inv->ws, s, &err, &got_lo, &got_hi);
         if (rc != 0) return fail(err);
         HImageDesc &d = inv->images[slot];
         d.data = inv->native_maps[k];
@@ -585,7 +586,7 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
         d.ay *= -1.0f;
         inv->native_memo[k] = rec;
         inv->native_memo_gen[k] = inv->input_generation;
-        inv->native_rows[k] = {want_lo, want_hi};
+        inv->native_rows[k] = {got_lo, got_hi};
         table_changed = true;
     }
     if (table_changed) {
