@@ -224,6 +224,8 @@ struct Generator {
                     else if (!strcmp(cn, "exp")) name = "mmf_exp_f32";
                     else if (!strcmp(cn, "log")) name = "mmf_log_f32";
                 }
+                if (lhs && lhs->type == Ty::Int && (!strcmp(cn, "floor") || !strcmp(cn, "ceil")))
+                    name = !strcmp(cn, "floor") ? "mm_floor_i" : "mm_ceil_i";      // x86 double -> int conversion
                 if (opt.fast_math_exact && !strcmp(cn, "pow") && lhs && lhs->type == Ty::Float && r.args.size() == 2 &&
                     r.args[0].type() == Ty::Float && r.args[1].type() == Ty::Float)
                     name = "mmf_pow_f32";

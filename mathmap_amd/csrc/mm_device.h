@@ -92,7 +92,12 @@ struct mm_args {
 // ---- op macros (opmacros.h:30-47) --------------------------------------------------
 #define NOP() (0.0)
 #define INT2FLOAT(x) ((float)(x))
-#define FLOAT2INT(x) ((int)(x))
+// C's float -> int conversion is undefined outside the int range; the reference runs on x86-64,
+// where cvttss2si returns INT_MIN ("integer indefinite") for NaN and out-of-range values, while
+// v_cvt_i32_f32 saturates and turns NaN into 0.  A pixel whose coordinate is NaN (0/0 at a
+// filter's singular point) must land outside the image like it does there, not on texel (0, 0).
+MM_DEV int mm_f2i(float x) { return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000; }
+#define FLOAT2INT(x) (mm_f2i((float)(x)))
 #define ADD(a, b) ((a) + (b))
 #define SUB(a, b) ((a) - (b))
 #define NEG(a) (-(a))
@@ -139,6 +144,10 @@ MM_DEV double mm_acosh(double a) { return acosh(a); }
 MM_DEV double mm_atanh(double a) { return atanh(a); }
 MM_DEV double mm_floor(double a) { return floor(a); }
 MM_DEV double mm_ceil(double a) { return ceil(a); }
+// floor / ceil assigned to an int variable: the C assignment converts the double with cvttsd2si
+MM_DEV int mm_d2i(double x) { return (x >= -2147483648.0 && x < 2147483648.0) ? (int)x : (int)0x80000000; }
+MM_DEV int mm_floor_i(double a) { return mm_d2i(floor(a)); }
+MM_DEV int mm_ceil_i(double a) { return mm_d2i(ceil(a)); }
 // GSL / GLib operators (mm_gslmath.h, restated; parity unpinned)
 MM_DEV mm_tup<2> mm_solve_linear_2(const mm_tup<4> &m, const mm_tup<2> &v) {
     double A[4], x[2];
@@ -475,16 +484,16 @@ MM_DEV color_t mm_orig_val_pixel(const mm_args &A, const mm_image_desc &d, float
     y = y + 0.5f;
 #endif
     // floor((double)x) of a float is the float floor: identical integer
-    if (HOT) return mm_get_pixel(A, d, (int)floorf(x), (int)floorf(y));
-    return mm_get_pixel_cold(A, d, (int)floorf(x), (int)floorf(y), frame);
+    if (HOT) return mm_get_pixel(A, d, mm_f2i(floorf(x)), mm_f2i(floorf(y)));
+    return mm_get_pixel_cold(A, d, mm_f2i(floorf(x)), mm_f2i(floorf(y)), frame);
 }
 
 template <bool HOT>
 MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
-    int x1 = (int)floorf(x), x2 = x1 + 1;     // == floor((double)x)
-    int y1 = (int)floorf(y), y2 = y1 + 1;
+    int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;     // == (int)floor((double)x) on x86-64
+    int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
     float x2fact = x - x1, y2fact = y - y1;
     // reference: 1.0 - x2fact in double, rounded to float: the double difference is exact,
     // so this is the correctly rounded float subtraction
@@ -545,9 +554,9 @@ MM_DEV mm_tup<4> mm_orig_val_d(const mm_args &A, float x, float y, mm_image img,
     if (img.idx < 0) { mm_tup<4> t; t.v[0] = t.v[1] = t.v[2] = t.v[3] = 1.0f; return t; }
     if (d.kind == MM_IMG_FLOATMAP) return mm_floatmap_pixel(d, x, y);
 #if MM_INTERSAMPLE
-    return mm_tuple_from_color(mm_orig_val_intersample_pixel<false>(A, d, x, y, (int)f));
+    return mm_tuple_from_color(mm_orig_val_intersample_pixel<false>(A, d, x, y, mm_f2i(f)));
 #else
-    return mm_tuple_from_color(mm_orig_val_pixel<false>(A, d, x, y, (int)f));
+    return mm_tuple_from_color(mm_orig_val_pixel<false>(A, d, x, y, mm_f2i(f)));
 #endif
 }
 // The fetch of the kernel's hot variant: the image is a bound drawable and the frame valid
@@ -574,8 +583,8 @@ MM_DEV mm_f2 mm_bytes_to_unit(mm_f2 k) {
 MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc &d, float x, float y) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
-    const int x1 = (int)floorf(x), x2 = x1 + 1;
-    const int y1 = (int)floorf(y), y2 = y1 + 1;
+    const int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;
+    const int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
     const float x2fact = x - x1, y2fact = y - y1;
     const float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
     const float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;

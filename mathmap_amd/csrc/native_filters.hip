@@ -91,7 +91,10 @@ __global__ void __launch_bounds__(256) k_render_drawable(const uint32_t *__restr
     x = (x + middle_x) * scale_x;
     y = -((y - middle_y) * scale_y);
     if (!supersampling) { x += 0.5; y += 0.5; }
-    const int ix = (int)floor((double)x), iy = (int)floor((double)y);
+    // cvttsd2si semantics for NaN / out-of-range (see mm_f2i in mm_device.h): INT_MIN, i.e. outside
+    const double fx = floor((double)x), fy = floor((double)y);
+    const int ix = (fx >= -2147483648.0 && fx < 2147483648.0) ? (int)fx : (int)0x80000000;
+    const int iy = (fy >= -2147483648.0 && fy < 2147483648.0) ? (int)fy : (int)0x80000000;
     uint32_t c;
     if (ix < 0 || ix >= sw) c = edge_x;
     else if (iy < 0 || iy >= sh) c = edge_y;

@@ -173,6 +173,54 @@ def test_edge_behaviours_match_oracle(ex, ey, intersample):
         del os.environ["MMHIP_SINGLE_PIXEL"]
 
 
+@pytest.mark.parametrize("intersample", [True, False])
+def test_nan_and_huge_coordinates_follow_x86_conversion(intersample):
+    """Sampling at NaN, +-inf and beyond-int coordinates: the reference converts with cvttss2si
+    (INT_MIN for all of them: outside the image -> edge colour), the device conversion saturates
+    and maps NaN to 0 unless told otherwise (mm_f2i); also floor() of such values.  NaN matches in
+    every edge mode; inf / > 2^31 px coordinates match with the nearest fetch and, for bilinear,
+    in COLOR edge mode -- with WRAP/REFLECT/ROTATE the bilinear weights themselves are garbage
+    (x - (float)INT_MIN) and the reference's byte is the low byte of a 64-bit conversion of ~1e32,
+    which the device path (a clamp) does not imitate: documented in DESIGN.md 4."""
+    w, h = 128, 64
+    img = W.synthetic_image(w, h, seed=8)
+    nan = "filter n (image in) q = exp(x * 1000 + 900) * 0; in(xy + xy:[q, 0]) end"
+    wild = ("filter n (image in) q = exp(x * 1000 + 900); big = x * 1000000 * 1000000 * 1000000 * 1000000 * 1000000; "
+            "k = floor(big) + floor(q * 0); in(xy + xy:[q, 0]) * 0.5 + in(xy:[big, y]) * 0.25 + in(xy * (1 + k * 0)) * 0.25 end")
+    colors = (0x30507090, 0xA0B0C0D0)
+    cases = [(nan, e) for e in ((0, 0), (1, 1), (2, 2), (3, 3), (1, 2))]
+    cases += [(wild, e) for e in (((0, 0),) if intersample else ((0, 0), (1, 1), (2, 2), (3, 3)))]
+    for src, (ex, ey) in cases:
+        flt = mm.Filter(src, intersample=intersample, edge_x=ex, edge_y=ey)
+        inv = flt.invoke(w, h)
+        inv.set_image("in", img)
+        inv.set_edge_colors(*colors)
+        got = inv.render()
+        want = CpuFilter(flt.ir_json).render(w, h, images={"in": img}, intersample=intersample, edge=(ex, ey), edge_colors=colors)
+        assert np.array_equal(got, want), (src[:40], ex, ey, stats(got, want))
+
+
+@pytest.mark.parametrize("size", [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (17, 2)])
+def test_degenerate_frame_sizes(size):
+    """One-pixel-wide / -high frames: (W-1)/2 = 0 makes the virtual coordinates inf or NaN in the
+    reference too; every workload must still agree with the oracle."""
+    w, h = size
+    img = np.ascontiguousarray(W.synthetic_image(max(w, 2), max(h, 2), seed=3)[:h, :w])
+    for name in ("mandelbrot", "ident", "pond", "droste", "gauss_direct"):
+        src = W.ALL[name]
+        needs = "image in" in src
+        uv = {"hdev": 0.9, "vdev": 0.8} if name == "gauss_direct" else {}
+        flt = mm.Filter(src)
+        inv = flt.invoke(w, h)
+        for k, v in uv.items():
+            inv.set(k, v)
+        if needs:
+            inv.set_image("in", img)
+        got = inv.render(t=0.2)
+        want = CpuFilter(flt.ir_json).render(w, h, uservals=uv, images={"in": img} if needs else {}, t=0.2)
+        assert stats(got, want)[0] <= 1, (name, size, stats(got, want))
+
+
 def test_nearest_sampling_matches_oracle():
     w, h = 300, 200
     img = W.synthetic_image(w, h, seed=5)
