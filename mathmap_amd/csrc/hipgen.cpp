@@ -196,7 +196,7 @@ struct Generator {
                 }
                 if (sl == PIXEL && hot_mode && hot_sites.count(stmt))
                     return "mm_orig_val_hot(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " + prim(r.args[2], sl) +
-                           ", " + vname(r.args[2].value) + "_desc)";
+                           ", " + vname(r.args[2].value) + "_desc, mm_bad)";
                 if (sl == PIXEL && !strcmp(cn, "ORIG_VAL") && r.args.size() == 4 && r.args[2].kind == Primary::Val &&
                     preloaded_desc.count(r.args[2].value))
                     return "mm_orig_val_d(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " + prim(r.args[2], sl) +
@@ -621,11 +621,12 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         // branch-free fetch their image loads are independent and overlap (one load per wave in
         // flight cannot cover HBM latency); rows past the end are computed on the last row and
         // simply not stored.  A.ppt is a multiple of MM_UNROLL (runtime.cpp).
-        auto emit_loop = [&](const char *ind) {
+        auto emit_loop = [&](const char *ind, bool hot) {
             std::string I = ind;
-            out << "#pragma unroll 1\n" << I << "for (int mm_p = 0; mm_p < A.ppt; mm_p += MM_UNROLL) {\n"
+            out << "#pragma unroll 1\n" << I << "for (; mm_p < A.ppt; mm_p += MM_UNROLL) {\n"
                 << I << "  mm_tup<4> mm_rt[MM_UNROLL];\n"
                 << I << "  float mm_y[MM_UNROLL];\n"
+                << I << "  bool mm_bad = false;   // a hot fetch met a NaN / inf / > 2^31 px coordinate\n"
                 << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {   // all row coordinates first: one wait\n"
                 << I << "    const int rl_raw = row0 + (mm_p + mm_u) * MM_TILE_H;\n"
                 << I << "    mm_y[mm_u] = A.ytab[rl_raw < A.num_rows ? rl_raw : A.num_rows - 1];\n"
@@ -640,7 +641,10 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
             stmts(code.body, PIXEL, (I + "    ").c_str());
             for (int i = 0; i < 4; ++i)
                 out << I << "    mm_rt[mm_u].v[" << i << "] = " << prim(Primary::V(code.result[i]), PIXEL) << ";\n";
-            out << I << "  }\n#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
+            out << I << "  }\n";
+            if (hot)
+                out << I << "  if (mm_bad) break;     // these pixels (and this work-item's remaining ones) take the generic loop below\n";
+            out << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
                 << I << "    // a row past the end was evaluated as the last row: storing it there again writes the\n"
                 << I << "    // same bytes, and keeps the pixel bodies free of a store guard the compiler would\n"
                 << I << "    // otherwise sink them (and their loads) into\n"
@@ -650,23 +654,25 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         // Hot variant: when every fetch through a preloaded descriptor reads a bound drawable
         // at a valid, frame-constant frame number (true for every ordinary render), those
         // conditions -- all wave-uniform -- are tested once here instead of inside each fetch,
-        // which leaves the unrolled pixel bodies free of branches.
+        // which leaves the unrolled pixel bodies free of branches.  The generic loop follows it and
+        // takes over from the same mm_p: for everything when the hot conditions do not hold, and for a
+        // work-item that met an invalid coordinate (mm_bad), whose garbage the reference converts in a
+        // way only the generic fetch imitates.
         std::vector<std::string> hot_conds;
         find_hot_fetches(code.body, hot_conds);
+        out << "  int mm_p = 0;\n";
         if (ks.unroll > 1 && !hot_conds.empty()) {
             out << "  bool mm_hot = true;\n";
             for (const std::string &c : hot_conds) out << "  mm_hot = mm_hot && " << c << ";\n";
             out << "  if (mm_hot) {\n";
             hot_mode = true;
-            emit_loop("    ");
+            emit_loop("    ", true);
             hot_mode = false;
-            out << "  } else {\n";
-            emit_loop("    ");
             out << "  }\n";
         } else {
             hot_sites.clear();
-            emit_loop("  ");
         }
+        emit_loop("  ", false);
         out << "}\n";
         finish_source();
     }

@@ -488,6 +488,17 @@ MM_DEV color_t mm_orig_val_pixel(const mm_args &A, const mm_image_desc &d, float
     return mm_get_pixel_cold(A, d, mm_f2i(floorf(x)), mm_f2i(floorf(y)), frame);
 }
 
+// (color_t)rintf(v) & 0xff as x86-64 computes it: cvttss2si to 64 bits, low byte.  For the
+// [0, 255.5) a sane bilinear sum lies in this is just the value; it matters when a coordinate is
+// NaN, infinite or beyond +-2^31 pixels, where the weights (x - (float)INT_MIN ...) and therefore
+// the sums are garbage the reference nevertheless converts deterministically: |v| >= 2^32 (and
+// NaN) gives 0 -- a float that large is a multiple of 2^9 --, a negative v the two's complement.
+MM_DEV color_t mm_x86_byte(float v) {
+    const float a = fabsf(v);
+    const unsigned u = (a < 4294967296.0f) ? (unsigned)a : 0u;
+    return ((v < 0.0f) ? (0u - u) : u) & 0xffu;
+}
+
 template <bool HOT>
 MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
     x = (x + d.middle_x) * d.scale_x;
@@ -515,6 +526,8 @@ MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_de
     r = r + RED(p2) * p2fact; g = g + GREEN(p2) * p2fact; b = b + BLUE(p2) * p2fact; a = a + ALPHA(p2) * p2fact;
     r = r + RED(p3) * p3fact; g = g + GREEN(p3) * p3fact; b = b + BLUE(p3) * p3fact; a = a + ALPHA(p3) * p3fact;
     r = r + RED(p4) * p4fact; g = g + GREEN(p4) * p4fact; b = b + BLUE(p4) * p4fact; a = a + ALPHA(p4) * p4fact;
+    if (x1 == (int)0x80000000 || y1 == (int)0x80000000)      // invalid coordinate: garbage sums, exact conversion
+        return MAKE_RGBA_COLOR(mm_x86_byte(rintf(r)), mm_x86_byte(rintf(g)), mm_x86_byte(rintf(b)), mm_x86_byte(rintf(a)));
     return MAKE_RGBA_COLOR((color_t)rintf(r) & 0xff, (color_t)rintf(g) & 0xff, (color_t)rintf(b) & 0xff,
                            (color_t)rintf(a) & 0xff);
 }
@@ -580,11 +593,14 @@ MM_DEV mm_f2 mm_bytes_to_unit(mm_f2 k) {
 // in the same order per channel (builtins.c:202-250), two channels per packed instruction;
 // the rounded channel value stays a float ((color_t)rintf(v) & 0xff is rintf(v) for the
 // [0, 255.5) a convex combination of bytes lies in; v_med3 keeps wild coordinates in range).
-MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc &d, float x, float y) {
+// `bad` is raised for a coordinate that is NaN / infinite / beyond +-2^31 pixels: the caller then
+// discards this result and re-evaluates the pixel through the generic path (mm_x86_byte above).
+MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc &d, float x, float y, bool &bad) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
     const int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;
     const int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
+    bad = bad || x1 == (int)0x80000000 || y1 == (int)0x80000000;
     const float x2fact = x - x1, y2fact = y - y1;
     const float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
     const float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
@@ -606,11 +622,11 @@ MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc 
     return t;
 }
 
-MM_DEV mm_tup<4> mm_orig_val_hot(const mm_args &A, float x, float y, mm_image img, const mm_image_desc &d) {
+MM_DEV mm_tup<4> mm_orig_val_hot(const mm_args &A, float x, float y, mm_image img, const mm_image_desc &d, bool &bad) {
     x *= img.resized ? img.xf : 1.0f;
     y *= img.resized ? img.yf : 1.0f;
 #if MM_INTERSAMPLE
-    return mm_intersample_tuple_hot(A, d, x, y);
+    return mm_intersample_tuple_hot(A, d, x, y, bad);
 #else
     return mm_tuple_from_color(mm_orig_val_pixel<true>(A, d, x, y, 0));
 #endif

@@ -131,11 +131,6 @@ def make_filter_ex(seed):
     src = "%s%sfilter fx%d (%s)\n  %s\n  %s\nend\n" % (helper, flag, seed, ", ".join(params), "\n  ".join(g.lines), result)
     src = src.replace("\\n", "\n")
     opts = dict(intersample=r.random() < 0.7, edge_x=r.choice([0, 0, 1, 2, 3]), edge_y=r.choice([0, 0, 1, 2, 3]))
-    if opts["intersample"]:
-        # random loops in pixel coordinates reach |coordinate| > 2^31 px, where bilinear + WRAP/REFLECT/
-        # ROTATE is the documented garbage-weights corner; sane-coordinate coverage of that
-        # combination is test_edge_behaviours_match_oracle
-        opts["edge_x"] = opts["edge_y"] = 0
     return src, images, opts
 
 

@@ -177,11 +177,10 @@ def test_edge_behaviours_match_oracle(ex, ey, intersample):
 def test_nan_and_huge_coordinates_follow_x86_conversion(intersample):
     """Sampling at NaN, +-inf and beyond-int coordinates: the reference converts with cvttss2si
     (INT_MIN for all of them: outside the image -> edge colour), the device conversion saturates
-    and maps NaN to 0 unless told otherwise (mm_f2i); also floor() of such values.  NaN matches in
-    every edge mode; inf / > 2^31 px coordinates match with the nearest fetch and, for bilinear,
-    in COLOR edge mode -- with WRAP/REFLECT/ROTATE the bilinear weights themselves are garbage
-    (x - (float)INT_MIN) and the reference's byte is the low byte of a 64-bit conversion of ~1e32,
-    which the device path (a clamp) does not imitate: documented in DESIGN.md 4."""
+    and maps NaN to 0 unless told otherwise (mm_f2i); also floor() of such values.  With WRAP/
+    REFLECT/ROTATE edges the bilinear weights themselves are garbage then (x - (float)INT_MIN) and
+    the reference's byte is the low byte of a 64-bit conversion of ~1e32: the branch-free fetch
+    flags such a pixel and the work-item redoes it in the generic loop (mm_x86_byte)."""
     w, h = 128, 64
     img = W.synthetic_image(w, h, seed=8)
     nan = "filter n (image in) q = exp(x * 1000 + 900) * 0; in(xy + xy:[q, 0]) end"
@@ -189,7 +188,7 @@ def test_nan_and_huge_coordinates_follow_x86_conversion(intersample):
             "k = floor(big) + floor(q * 0); in(xy + xy:[q, 0]) * 0.5 + in(xy:[big, y]) * 0.25 + in(xy * (1 + k * 0)) * 0.25 end")
     colors = (0x30507090, 0xA0B0C0D0)
     cases = [(nan, e) for e in ((0, 0), (1, 1), (2, 2), (3, 3), (1, 2))]
-    cases += [(wild, e) for e in (((0, 0),) if intersample else ((0, 0), (1, 1), (2, 2), (3, 3)))]
+    cases += [(wild, e) for e in ((0, 0), (1, 1), (2, 2), (3, 3), (2, 1))]
     for src, (ex, ey) in cases:
         flt = mm.Filter(src, intersample=intersample, edge_x=ex, edge_y=ey)
         inv = flt.invoke(w, h)
