@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace mm {
@@ -120,8 +121,14 @@ __global__ void __launch_bounds__(256) k_render_drawable(const uint32_t *__restr
 // exact operation order); the only parallelism is lines x channels, so memory latency is
 // hidden by prefetching IIR_U steps ahead in registers rather than by occupancy.
 #define IIR_U 16
+#ifndef IIR_PF
+#define IIR_PF 3          // blocks a causal sweep's loads run ahead of its arithmetic
+#endif
 
-struct LineArgs { int n; int lines; };
+// seg: segment length (a multiple of IIR_U, >= n when the lines are not split), halo: warm-up
+// steps a segment's sweeps take before they reach it (a multiple of IIR_U), lane_blocks: 256-lane
+// workgroups per segment.
+struct LineArgs { int n; int lines; int seg; int halo; unsigned lane_blocks; };
 
 __device__ __forceinline__ double iir_step(double s0, double s1, double s2, double s3, double s4, double v1, double v2,
                                            double v3, double v4, const double *n, const double *d) {
@@ -155,13 +162,24 @@ __device__ __forceinline__ double iir_edge_step(int j, double s0, double s1, dou
 // element is consumed, so a block's 16 prefetches stay in flight while the previous block is
 // computed); decode() turns the loaded word into the float the recurrence sees.
 // A float map laid out in[k][line][ch] ...
+//
+// Addressing: element k of a lane is base[k * stride + lane] with `base`, `stride` and (in the
+// sweeps) k wave-uniform, so the row address is scalar arithmetic and the load takes the scalar
+// base + 32-bit lane offset form.  row()/at() let a block of 16 consecutive k share one row address:
+// with a single wave on a SIMD every instruction, scalar ones included, takes an issue slot from
+// the recurrence, and per-element 64-bit index arithmetic was a third of a block's instructions.
 struct MapSrc {
     typedef float raw_t;
-    const float *p;        // already offset to this lane's (line, channel)
-    long stride;           // lines * 4
-    __device__ __forceinline__ raw_t fetch(int k) const { return p[(long)k * stride]; }
+    const float *p;        // the map (uniform)
+    unsigned stride;       // lines * 4
+    unsigned lane;         // line * 4 + channel
+    __device__ __forceinline__ raw_t fetch(int k) const { return p[(size_t)k * stride + lane]; }
+    __device__ __forceinline__ const raw_t *row(int k) const { return p + (size_t)k * stride; }
+    __device__ __forceinline__ raw_t at(const raw_t *r, int u) const {       // scalar base + 32-bit byte offset
+        return *(const raw_t *)((const char *)r + (((unsigned)u * stride + lane) << 2));
+    }
     __device__ __forceinline__ float decode(raw_t v) const { return v; }
-    __device__ __forceinline__ MapSrc for_lane(long L) const { return MapSrc{p + L, stride}; }
+    __device__ __forceinline__ MapSrc for_lane(long L) const { return MapSrc{p, stride, (unsigned)L}; }
 };
 // ... or the input drawable itself when render_image's coordinate mapping (builtins.c:303-343)
 // is the identity -- a drawable of the render size, which the host establishes by evaluating
@@ -169,13 +187,18 @@ struct MapSrc {
 // render_image is then fused into the first pass: 4 instead of 16 B/px read, no 4.3 GB map.
 struct DrawableSrc {
     typedef uint32_t raw_t;
-    const uint32_t *p;     // offset to this lane's column
-    int sw;                // source pitch in pixels
+    const uint32_t *p;     // the drawable's window (uniform)
+    unsigned sw;           // source pitch in pixels
+    unsigned lane;         // column
     int shift;             // 24 - 8*channel
-    __device__ __forceinline__ raw_t fetch(int k) const { return p[(long)k * sw]; }
+    __device__ __forceinline__ raw_t fetch(int k) const { return p[(size_t)k * sw + lane]; }
+    __device__ __forceinline__ const raw_t *row(int k) const { return p + (size_t)k * sw; }
+    __device__ __forceinline__ raw_t at(const raw_t *r, int u) const {
+        return *(const raw_t *)((const char *)r + (((unsigned)u * sw + lane) << 2));
+    }
     // TUPLE_FROM_COLOR: (c >> shift & 0xff) / 255.0 == ... * (1.0 / 255.0) for all 256 bytes (enumerated)
     __device__ __forceinline__ float decode(raw_t c) const { return (float)((double)((c >> shift) & 0xff) * (1.0 / 255.0)); }
-    __device__ __forceinline__ DrawableSrc for_lane(long L) const { return DrawableSrc{p + (L >> 2), sw, 24 - 8 * (int)(L & 3)}; }
+    __device__ __forceinline__ DrawableSrc for_lane(long L) const { return DrawableSrc{p, sw, (unsigned)(L >> 2), 24 - 8 * (int)(L & 3)}; }
 };
 
 // Causal sweep.  Nothing but the recurrence state at every IIR_U-th step leaves the kernel:
@@ -183,49 +206,92 @@ struct DrawableSrc {
 // the 8 a full f64 partial-sum map would take.  The anticausal kernel re-runs the causal
 // recurrence block by block from these checkpoints (same operations, same order: identical
 // values) right before it needs them.
-template <class Src>
-__device__ __forceinline__ void causal_sweep(const Src &src, double *__restrict__ ck, long stride, int n, const IirCoef &c) {
-    const float initial = src.decode(src.fetch(0));
-    double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-    typename Src::raw_t cur[IIR_U], nxt[IIR_U];
+// The segment [s0, s1) of the line: the sweep starts at k0 = max(0, s0 - halo), at k0 > 0 as if k0
+// were the line's edge (see the segment note at k_iir_causal), and stores the checkpoints of the
+// segment's own blocks only.
+struct IirState { double s1, s2, s3, s4, v1, v2, v3, v4; };
+
+// IIR_PF + 1 consecutive blocks starting at kb0, ring slot j holding block kb0 + j*IIR_U.  A block's
+// 16 loads are issued IIR_PF blocks before the block is computed: one block of arithmetic (~0.8 us) is
+// shorter than a trip to HBM under load, and with one wave per SIMD nothing else hides the
+// difference.  The ring is indexed statically, so it lives in registers (a lone wave may use all
+// 512).  FAST: every block of the group and every block prefetched by it is a full interior block of
+// the segment -- straight-line code without a branch, which is also what lets the compiler count
+// the outstanding loads exactly instead of waiting for all of them at a join.
+template <bool FAST, class Src>
+__device__ __forceinline__ void causal_group(const Src &src, typename Src::raw_t (&ring)[IIR_PF + 1][IIR_U], IirState &st,
+                                             double *__restrict__ ck, unsigned stride, unsigned lane, int kb0, int k0, int s0,
+                                             int s1, float initial, const IirCoef &c) {
+    double s1_ = st.s1, s2 = st.s2, s3 = st.s3, s4 = st.s4, v1 = st.v1, v2 = st.v2, v3 = st.v3, v4 = st.v4;
 #pragma unroll
-    for (int u = 0; u < IIR_U; ++u) cur[u] = src.fetch(u < n ? u : 0);
-    for (int kb = 0; kb < n; kb += IIR_U) {
+    for (int j = 0; j <= IIR_PF; ++j) {
+        const int kb = kb0 + j * IIR_U;
+        if (FAST || kb < s1) {
+            typename Src::raw_t *cur = ring[j], *far = ring[(j + IIR_PF) % (IIR_PF + 1)];
+            const int kf = kb + IIR_PF * IIR_U;
+            if (FAST || kf + IIR_U <= s1) {
+                const typename Src::raw_t *r = src.row(kf);
 #pragma unroll
-        for (int u = 0; u < IIR_U; ++u) nxt[u] = src.fetch(kb + IIR_U + u < n ? kb + IIR_U + u : 0);   // past the end: unused
-        if (kb > 0) {
-            double *q = ck + (long)(kb / IIR_U) * 4 * stride;
-            q[0] = v1;
-            q[stride] = v2;
-            q[2 * stride] = v3;
-            q[3 * stride] = v4;
-        }
-        if (kb > 0 && kb + IIR_U <= n) {
-            // interior block: no edge steps, no bounds -- straight-line code, the state "shifts"
-            // are register renames
+                for (int u = 0; u < IIR_U; ++u) far[u] = src.at(r, u);
+            } else {
 #pragma unroll
-            for (int u = 0; u < IIR_U; ++u) {
-                const double s0 = (double)src.decode(cur[u]);
-                const double acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
-                s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-                v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                for (int u = 0; u < IIR_U; ++u) far[u] = src.fetch(kf + u < s1 ? kf + u : k0);   // past the end: unused
             }
-        } else {
+            if (FAST || (kb > 0 && kb >= s0)) {
+                double *q = ck + (size_t)(kb / IIR_U) * 4 * stride;
+                q[lane] = v1;
+                q[stride + lane] = v2;
+                q[2 * stride + lane] = v3;
+                q[3 * stride + lane] = v4;
+            }
+            if (FAST || (kb > k0 && kb + IIR_U <= s1)) {
+                // interior block: no edge steps, no bounds; the state "shifts" are register renames
 #pragma unroll
-            for (int u = 0; u < IIR_U; ++u) {
-                const int k = kb + u;
-                if (k < n) {
-                    const double s0 = (double)src.decode(cur[u]);
-                    const double acc = (kb == 0 && u < 4) ? iir_edge_step(u, s0, s1, s2, s3, v1, v2, v3, c.n_p, c.d_p, c.bd_p, initial)
-                                                           : iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
-                    s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                for (int u = 0; u < IIR_U; ++u) {
+                    const double s0v = (double)src.decode(cur[u]);
+                    const double acc = iir_step(s0v, s1_, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
+                    s4 = s3; s3 = s2; s2 = s1_; s1_ = s0v;
                     v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < IIR_U; ++u) {
+                    const int k = kb + u;
+                    if (k < s1) {
+                        const double s0v = (double)src.decode(cur[u]);
+                        const double acc = (kb == k0 && u < 4) ? iir_edge_step(u, s0v, s1_, s2, s3, v1, v2, v3, c.n_p, c.d_p, c.bd_p, initial)
+                                                                : iir_step(s0v, s1_, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
+                        s4 = s3; s3 = s2; s2 = s1_; s1_ = s0v;
+                        v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < IIR_U; ++u) cur[u] = nxt[u];
     }
+    st = IirState{s1_, s2, s3, s4, v1, v2, v3, v4};
+}
+
+template <class Src>
+__device__ __forceinline__ void causal_sweep(const Src &src, double *__restrict__ ck, unsigned stride, unsigned lane, int k0,
+                                             int s0, int s1, const IirCoef &c) {
+    const float initial = src.decode(src.fetch(k0));
+    IirState st{0, 0, 0, 0, 0, 0, 0, 0};
+    typename Src::raw_t ring[IIR_PF + 1][IIR_U];
+#pragma unroll
+    for (int j = 0; j < IIR_PF; ++j)
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) {
+            const int k = k0 + j * IIR_U + u;
+            ring[j][u] = src.fetch(k < s1 ? k : k0);
+        }
+    const int G = (IIR_PF + 1) * IIR_U;
+    int kb0 = k0;
+    do {        // the group with the edge steps, and a segment's warm-up groups (no checkpoints)
+        causal_group<false>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
+        kb0 += G;
+    } while (kb0 < s0 && kb0 < s1);
+    for (; kb0 + (2 * IIR_PF + 1) * IIR_U <= s1; kb0 += G) causal_group<true>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
+    for (; kb0 < s1; kb0 += G) causal_group<false>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
 }
 
 // One block of the causal recurrence re-run from its checkpoint (block 0: from the edge).
@@ -262,75 +328,130 @@ __device__ __forceinline__ void rerun_block(const Src &src, int b, int n, const 
 // values are re-run -- two independent dependency chains interleaved step by step, which is
 // what fills the f64 pipeline of a SIMD that holds a single wave -- and block b-2 is in flight
 // from memory.
+// Segment [sg0, sg1) of the line: the anticausal recurrence starts at k1 - 1, k1 = min(n, sg1 + halo)
+// (at k1 < n as if k1 were the line's end) and runs unrecorded down to sg1 first.
 template <class Src>
-__device__ __forceinline__ void anticausal_sweep(const Src &src, const double *__restrict__ ck, long stride, int n,
+__device__ __forceinline__ void anticausal_sweep(const Src &src, const double *__restrict__ ck, unsigned stride, unsigned clane,
+                                                 int n, int sg0, int sg1, int k1,
                                                  const IirCoef &c, float *tw, int lane, long line0, int lines,
                                                  float *__restrict__ outT, bool active) {
     typedef typename Src::raw_t raw_t;
     const int ll = lane >> 2, ch = lane & 3;                // line within the wave's 16, channel
-    const float initial_m = src.decode(src.fetch(n - 1)), initial_p = src.decode(src.fetch(0));
+    const float initial_m = src.decode(src.fetch(k1 - 1)), initial_p = src.decode(src.fetch(0));
     double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;      // anticausal state
-    const int nblocks = (n + IIR_U - 1) / IIR_U;
-    raw_t cur_s[IIR_U], nxt_s[IIR_U], nn_s[IIR_U], nxt4[4], nn4[4];
-    double nxt_ck[4], nn_ck[4], vc_cur[IIR_U], vc_nxt[IIR_U];
-    auto load_block = [&](int blk, raw_t *in, raw_t *r4, double *ckv) {
+    const int bbeg = sg0 / IIR_U, nblocks = (sg1 + IIR_U - 1) / IIR_U;          // this segment's blocks
+    if (k1 > sg1) {
+        raw_t cur_s[IIR_U], nxt_s[IIR_U];
+        // warm-up over [sg1, k1): sg1 is a block boundary here (only the last segment ends elsewhere, and
+        // it has no warm-up)
+        const int wend = (k1 + IIR_U - 1) / IIR_U;
+#pragma unroll
+        for (int u = 0; u < IIR_U; ++u) cur_s[u] = src.fetch((wend - 1) * IIR_U + u < k1 ? (wend - 1) * IIR_U + u : sg1);
+        for (int b = wend - 1; b >= nblocks; --b) {
+            const int kb = b * IIR_U;
+#pragma unroll
+            for (int u = 0; u < IIR_U; ++u) nxt_s[u] = src.fetch(b > nblocks ? kb - IIR_U + u : sg1);
+            if (kb + 2 * IIR_U <= k1) {
+#pragma unroll
+                for (int u = IIR_U - 1; u >= 0; --u) {
+                    const double s0 = (double)src.decode(cur_s[u]);
+                    const double acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
+                    s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                    v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                }
+            } else {
+#pragma unroll
+                for (int u = IIR_U - 1; u >= 0; --u) {
+                    const int k = kb + u;
+                    if (k < k1) {
+                        const int j = k1 - 1 - k;
+                        const double s0 = (double)src.decode(cur_s[u]);
+                        double acc;
+                        if (j < 4) acc = iir_edge_step(j, s0, s1, s2, s3, v1, v2, v3, c.n_m, c.d_m, c.bd_m, initial_m);
+                        else acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
+                        s4 = s3; s3 = s2; s2 = s1; s1 = s0;
+                        v4 = v3; v3 = v2; v2 = v1; v1 = acc;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < IIR_U; ++u) cur_s[u] = nxt_s[u];
+        }
+    }
+    // Pipeline slots.  At step b one slot is `cur` (block b: inputs and re-run causal values), one is
+    // `nxt` (block b-1: inputs, the 4 inputs before it and its checkpoint; its causal values are re-run
+    // during the step) and one is `far` (block b-2, being loaded).  The roles rotate through three
+    // statically indexed slots -- three steps are one group of straight-line code -- so the
+    // rotation costs no register moves.
+    struct Slot { raw_t s[IIR_U]; raw_t r4[4]; double ck[4]; double vc[IIR_U]; };
+    Slot slot[3];
+    auto load_block = [&](auto fast, int blk, Slot &o) {
         const int kb = blk * IIR_U;
+        if (decltype(fast)::value || (blk > 0 && kb + IIR_U <= n)) {
+            const raw_t *r = src.row(kb - 4);
+            const double *q = ck + (size_t)blk * 4 * stride;
 #pragma unroll
-        for (int u = 0; u < IIR_U; ++u) in[u] = src.fetch(kb + u < n ? kb + u : 0);
+            for (int i = 0; i < 4; ++i) {
+                o.r4[i] = src.at(r, i);
+                o.ck[i] = *(const double *)((const char *)q + (((unsigned)i * stride + clane) << 3));
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r4[i] = src.fetch(blk > 0 ? kb - 4 + i : 0);
-            ckv[i] = blk > 0 ? ck[((long)blk * 4 + i) * stride] : 0.0;
+            for (int u = 0; u < IIR_U; ++u) o.s[u] = src.at(r, 4 + u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < IIR_U; ++u) o.s[u] = src.fetch(kb + u < n ? kb + u : 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o.r4[i] = src.fetch(blk > 0 ? kb - 4 + i : 0);
+                o.ck[i] = blk > 0 ? ck[((size_t)blk * 4 + i) * stride + clane] : 0.0;
+            }
         }
     };
     auto interior_causal = [&](int blk) { return blk > 0 && (blk + 1) * IIR_U <= n; };
-    {   // prologue: the last block's inputs and causal values, the one before it on its way
-        raw_t r4[4];
-        double ckv[4];
-        load_block(nblocks - 1, cur_s, r4, ckv);
-        if (nblocks > 1) load_block(nblocks - 2, nxt_s, nxt4, nxt_ck);
-        rerun_block<true>(src, nblocks - 1, n, cur_s, r4, ckv, c, initial_p, vc_cur);
-    }
-    for (int b = nblocks - 1; b >= 0; --b) {
+    // One step: anticausal steps of block b (slot cur) next to the causal re-run of block b-1 (slot nxt),
+    // loads of block b-2 (slot far), 16 x 16 transposed write.  FAST: b-2 is a full block with a
+    // checkpoint and block b lies at least a block inside [.., k1) -- no edge steps, no bounds.
+    auto step = [&](auto fast, int b, Slot &cur, Slot &nxt, Slot &far) {
+        constexpr bool FAST = decltype(fast)::value;
         const int kb = b * IIR_U;
-        if (b > 1) load_block(b - 2, nn_s, nn4, nn_ck);
-        if (b > 0 && kb + 2 * IIR_U <= n && interior_causal(b - 1)) {
+        if (FAST || b - 2 >= bbeg) load_block(fast, b - 2, far);
+        if (FAST || (b > bbeg && kb + 2 * IIR_U <= k1 && interior_causal(b - 1))) {
             // both chains unguarded: causal step u of block b-1 next to anticausal step 15-u of block b
-            double cs1 = src.decode(nxt4[3]), cs2 = src.decode(nxt4[2]), cs3 = src.decode(nxt4[1]), cs4 = src.decode(nxt4[0]);
-            double cv1 = nxt_ck[0], cv2 = nxt_ck[1], cv3 = nxt_ck[2], cv4 = nxt_ck[3];
+            double cs1 = src.decode(nxt.r4[3]), cs2 = src.decode(nxt.r4[2]), cs3 = src.decode(nxt.r4[1]), cs4 = src.decode(nxt.r4[0]);
+            double cv1 = nxt.ck[0], cv2 = nxt.ck[1], cv3 = nxt.ck[2], cv4 = nxt.ck[3];
 #pragma unroll
             for (int u = 0; u < IIR_U; ++u) {
                 {
-                    const double s0 = (double)src.decode(nxt_s[u]);
+                    const double s0 = (double)src.decode(nxt.s[u]);
                     const double acc = iir_step(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
-                    vc_nxt[u] = acc;
+                    nxt.vc[u] = acc;
                     cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
                     cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
                 }
                 {
                     const int ua = IIR_U - 1 - u;
-                    const double s0 = (double)src.decode(cur_s[ua]);
+                    const double s0 = (double)src.decode(cur.s[ua]);
                     const double acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
-                    tw[ll * (IIR_U * 4 + 4) + ua * 4 + ch] = (float)(vc_cur[ua] + acc);   // transfer_pixels, gauss.c:117-124
+                    tw[ll * (IIR_U * 4 + 4) + ua * 4 + ch] = (float)(cur.vc[ua] + acc);   // transfer_pixels, gauss.c:117-124
                     s4 = s3; s3 = s2; s2 = s1; s1 = s0;
                     v4 = v3; v3 = v2; v2 = v1; v1 = acc;
                 }
             }
         } else {
-            if (b > 0) {
-                if (interior_causal(b - 1)) rerun_block<false>(src, b - 1, n, nxt_s, nxt4, nxt_ck, c, initial_p, vc_nxt);
-                else rerun_block<true>(src, b - 1, n, nxt_s, nxt4, nxt_ck, c, initial_p, vc_nxt);
+            if (b > bbeg) {
+                if (interior_causal(b - 1)) rerun_block<false>(src, b - 1, n, nxt.s, nxt.r4, nxt.ck, c, initial_p, nxt.vc);
+                else rerun_block<true>(src, b - 1, n, nxt.s, nxt.r4, nxt.ck, c, initial_p, nxt.vc);
             }
 #pragma unroll
             for (int u = IIR_U - 1; u >= 0; --u) {
                 const int k = kb + u;
                 if (k < n) {
-                    const int j = n - 1 - k;                     // steps from the end
-                    const double s0 = (double)src.decode(cur_s[u]);
+                    const int j = k1 - 1 - k;                    // steps from the end (of the line, or of the warm-up)
+                    const double s0 = (double)src.decode(cur.s[u]);
                     double acc;
                     if (j < 4) acc = iir_edge_step(j, s0, s1, s2, s3, v1, v2, v3, c.n_m, c.d_m, c.bd_m, initial_m);
                     else acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
-                    tw[ll * (IIR_U * 4 + 4) + u * 4 + ch] = (float)(vc_cur[u] + acc);   // transfer_pixels, gauss.c:117-124
+                    tw[ll * (IIR_U * 4 + 4) + u * 4 + ch] = (float)(cur.vc[u] + acc);   // transfer_pixels, gauss.c:117-124
                     s4 = s3; s3 = s2; s2 = s1; s1 = s0;
                     v4 = v3; v3 = v2; v2 = v1; v1 = acc;
                 }
@@ -346,7 +467,7 @@ __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *_
             const int tl = i * 4 + (lane >> 4), kk = lane & 15;
             const long line = line0 + tl;
             const int k = kb + kk;
-            if (line < lines && k < n) {
+            if (line < lines && (FAST || k < n)) {
                 const float4 v = *(const float4 *)&tw[tl * (IIR_U * 4 + 4) + kk * 4];
                 *(float4 *)&outT[(line * (long)n + k) * 4] = v;
             }
@@ -354,20 +475,40 @@ __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int u = 0; u < IIR_U; ++u) { cur_s[u] = nxt_s[u]; nxt_s[u] = nn_s[u]; vc_cur[u] = vc_nxt[u]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { nxt4[i] = nn4[i]; nxt_ck[i] = nn_ck[i]; }
-    }
+    };
+    auto group = [&](auto fast, int b) {
+        constexpr bool FAST = decltype(fast)::value;
+        step(fast, b, slot[0], slot[1], slot[2]);
+        if (FAST || b - 1 >= bbeg) step(fast, b - 1, slot[1], slot[2], slot[0]);
+        if (FAST || b - 2 >= bbeg) step(fast, b - 2, slot[2], slot[0], slot[1]);
+    };
+    // prologue: the last block's inputs and causal values, the one before it on its way
+    load_block(std::false_type{}, nblocks - 1, slot[0]);
+    if (nblocks - 1 > bbeg) load_block(std::false_type{}, nblocks - 2, slot[1]);
+    rerun_block<true>(src, nblocks - 1, n, slot[0].s, slot[0].r4, slot[0].ck, c, initial_p, slot[0].vc);
+    int b = nblocks - 1;
+    const int fast_floor = (bbeg > 1 ? bbeg : 1) + 4;         // lowest b whose group is all-FAST: b-4 >= max(bbeg, 1)
+    for (; b >= bbeg && b * IIR_U + 2 * IIR_U > k1; b -= 3) group(std::false_type{}, b);      // the group at the line's end
+    for (; b >= fast_floor; b -= 3) group(std::true_type{}, b);
+    for (; b >= bbeg; b -= 3) group(std::false_type{}, b);
     (void)active;
 }
 
+// Segments (optional, see plan_segments).  A frame offers lines x 4 independent recurrences -- one
+// wave per SIMD at 16384^2, an eighth of the machine at 2048^2.  A line can be split into segments
+// that are swept concurrently: a segment's sweeps start `halo` steps before (causal) / after
+// (anticausal) it, from the start-up the reference uses at a line's edge.  The recurrences' poles
+// are exp(-1.783/sigma) and exp(-1.723/sigma) (gauss.c:57-58), so after halo = 22.7 sigma steps the
+// influence of the different start has decayed by e^-39 ~ 1e-17 before the first value that is
+// kept.  The true ends of a line keep the reference's start-up.
 template <class Src>
 __global__ void __launch_bounds__(256) k_iir_causal(Src in, double *__restrict__ ckpt, LineArgs g, IirCoef c) {
-    const long L = (long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned sgi = blockIdx.x / g.lane_blocks, lb = blockIdx.x % g.lane_blocks;
+    const long L = (long)lb * 256 + threadIdx.x;
     const long stride = (long)g.lines * 4;
     if (L >= stride) return;
-    causal_sweep(in.for_lane(L), ckpt + L, stride, g.n, c);
+    const int s0 = (int)sgi * g.seg, s1 = min(g.n, s0 + g.seg), k0 = max(0, s0 - g.halo);
+    causal_sweep(in.for_lane(L), ckpt, (unsigned)stride, (unsigned)L, k0, s0, s1, c);
 }
 
 template <class Src>
@@ -375,14 +516,50 @@ __global__ void __launch_bounds__(256) k_iir_anticausal_T(Src in, const double *
                                                           LineArgs g, IirCoef c) {
     // wave-private staging tile: 16 lines x IIR_U steps x 4 channels, line stride padded by 4 floats
     __shared__ float tile[4][16 * (IIR_U * 4 + 4)];
-    const long L = (long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned sgi = blockIdx.x / g.lane_blocks, lb = blockIdx.x % g.lane_blocks;
+    const long L = (long)lb * 256 + threadIdx.x;
     const long stride = (long)g.lines * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long line0 = ((long)blockIdx.x * 256 + (long)wave * 64) >> 2;   // first line of this wave
+    const long line0 = ((long)lb * 256 + (long)wave * 64) >> 2;   // first line of this wave
     const bool active = L < stride;
     const long Lc = active ? L : 0;      // idle lanes of the last wave shadow lane 0; their tile rows are never written out
-    anticausal_sweep(in.for_lane(Lc), ckpt + Lc, stride, g.n, c, tile[wave], lane, line0, g.lines, outT, active);
+    const int s0 = (int)sgi * g.seg, s1 = min(g.n, s0 + g.seg), k1 = s1 < g.n ? min(g.n, s1 + g.halo) : g.n;
+    anticausal_sweep(in.for_lane(Lc), ckpt, (unsigned)stride, (unsigned)Lc, g.n, s0, s1, k1, c, tile[wave], lane, line0, g.lines, outT, active);
 }
+
+// How to split lines of n steps, `lines` of them, for a recurrence of standard deviation sigma.
+// Off by default -- one segment, every value identical to the reference's: a warmed-up segment start
+// agrees with the full sweep only to the recurrence's own rounding-noise floor (~1e-14 relative in
+// f64: rounding differences are re-amplified by the 4th-order recurrence and never die out
+// completely), so 1e-7 (sigma 7 px) to 3e-6 (sigma 20 px) of the float32 results then round the other
+// way by one ulp.  MMHIP_GAUSS_SEGMENTS=auto picks the count by the model below (a sweep costs segment
+// + halo steps, at a rate set by the waves a SIMD holds: 1024 SIMDs, and a second wave hides the
+// first one's scalar and memory instructions), =N forces N.  Measured at 16384^2, sigma 20 px: 8.85 ->
+// 8.13 ms with two segments; the gain is large only for frames too small to give every SIMD a wave.
+LineArgs plan_segments(int n, int lines, float sigma) {
+    LineArgs g{n, lines, ((n + IIR_U - 1) / IIR_U) * IIR_U, 0, (unsigned)(((long)lines * 4 + 255) / 256)};
+    const char *env = getenv("MMHIP_GAUSS_SEGMENTS");
+    if (!env || !*env) return g;
+    const int forced = strcmp(env, "auto") ? atoi(env) : 0;
+    if (strcmp(env, "auto") && forced <= 1) return g;
+    const int halo = (((int)ceil(22.7 * (double)sigma) + 2 + IIR_U - 1) / IIR_U) * IIR_U;
+    const double waves = (double)g.lane_blocks * 4.0;
+    double best = 0.0;
+    for (int ns = 1; ns <= 64; ++ns) {
+        const int seg = (((n + ns - 1) / ns + IIR_U - 1) / IIR_U) * IIR_U;
+        if (ns > 1 && (seg < halo || (long)seg * (ns - 1) >= n)) break;     // too short to pay / empty last segment
+        const double per_simd = ceil(waves * ns / 1024.0);
+        const double cost = (double)(seg + (ns > 1 ? halo : 0)) * std::max(1.0, 0.53 * per_simd);
+        if (forced > 0 ? ns == forced : (ns == 1 || cost < best * 0.97)) {
+            best = cost;
+            g.seg = seg;
+            g.halo = ns > 1 ? halo : 0;
+        }
+    }
+    return g;
+}
+
+unsigned segment_count(const LineArgs &g) { return (unsigned)((g.n + g.seg - 1) / g.seg); }
 
 // ---- K5: FIR path for sigma < 0.5 px on either axis (gauss.c:264-639) ----------------------------
 // make_rle_curve on the host (double exp, float taps), then per axis: a statistics kernel
@@ -606,19 +783,21 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         if (y1 <= y0) return 0;
     }
     const int hn = y1 - y0;
+    // the scan kernels index a block of rows with 32-bit element offsets (MapSrc::at)
+    if ((long)std::max(w, hn) * 4 * 20 * 8 >= (1L << 32)) { *err = "gaussian_blur: frame too large for the scan kernels"; return -1; }
     // vertical pass first (gauss.c:155-201): lines = columns, n = rows of the window; result transposed
     // into mapT[w][hn][4].  Its two sweeps read the input where it lies: the float map, or --
     // identity mapping -- the drawable itself: no intermediate map, 4 instead of 16 B/px.
     find_iir_constants(c, vs);
     {
-        LineArgs g{hn, w};
-        const unsigned blocks = (unsigned)(((long)w * 4 + 255) / 256);
+        const LineArgs g = plan_segments(hn, w, vs);
+        const unsigned blocks = g.lane_blocks * segment_count(g);
         if (in.kind == IMG_FLOATMAP || !identity) {
-            const MapSrc src{(in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map) + (long)y0 * w * 4, (long)w * 4};
+            const MapSrc src{(in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map) + (long)y0 * w * 4, (unsigned)w * 4u, 0u};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
             k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
         } else {
-            const DrawableSrc src{(const uint32_t *)in.data + (long)y0 * in.w, in.w, 0};
+            const DrawableSrc src{(const uint32_t *)in.data + (long)y0 * in.w, (unsigned)in.w, 0u, 0};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
             k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
         }
@@ -627,9 +806,9 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
     // restores the original layout, written to rows [y0, y1) of out_map
     find_iir_constants(c, hs);
     {
-        LineArgs g{w, hn};
-        const unsigned blocks = (unsigned)(((long)hn * 4 + 255) / 256);
-        const MapSrc src{mapT, (long)hn * 4};
+        const LineArgs g = plan_segments(w, hn, hs);
+        const unsigned blocks = g.lane_blocks * segment_count(g);
+        const MapSrc src{mapT, (unsigned)hn * 4u, 0u};
         k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
         k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c);
     }

@@ -80,17 +80,28 @@ def test_hip_matches_oracle(name, uv, tol, size):
     assert mx <= tol or frac < 1e-4, "%s %s: max %d, %d differ, %d by >1" % (name, uv, mx, nd, n1)
 
 
-@pytest.mark.parametrize("size", [(37, 19), (64, 48), (129, 65), (5, 3), (16, 16), (17, 33), (300, 7)])
-def test_gauss_iir_float_map_is_bit_exact(size):
+@pytest.mark.parametrize("segments", [None, "auto"])
+@pytest.mark.parametrize("size", [(37, 19), (64, 48), (129, 65), (5, 3), (16, 16), (17, 33), (300, 7), (700, 523),
+                                  (1037, 650, 11.0, 7.5), (2051, 1500, 20.0, 12.75)])
+def test_gauss_iir_float_map_is_bit_exact(size, segments, monkeypatch):
     """The recursive Gaussian keeps the reference's operation order in f64 (gauss.c:126-262), so
     the blurred float map -- read back through float-map output, no byte quantisation -- must
     equal the oracle's bit for bit; sizes below, at and across the 16-step block boundaries of
-    the scan kernels."""
+    the scan kernels.  With MMHIP_GAUSS_SEGMENTS=auto lines of 2 * (22.7 sigma + 2) steps or more
+    are split into concurrently swept segments (the last three sizes, and the rows of 300 x 7): a
+    segment's warmed-up start agrees with the full sweep to ~1e-14 relative in f64 (the recurrence's
+    own rounding-noise floor), so 1e-7 (sigma 7 px) to 3e-6 (sigma 20 px) of the float32 values round
+    the other way by one ulp there; tolerance of that mode: <= 1 ulp on <= 1e-5 of the values."""
+    if segments:
+        monkeypatch.setenv("MMHIP_GAUSS_SEGMENTS", segments)
+    else:
+        monkeypatch.delenv("MMHIP_GAUSS_SEGMENTS", raising=False)
     import ctypes as C
     from mathmap_amd._lib import lib
-    w, h = size
+    w, h = size[:2]
+    sx, sy = size[2:] if len(size) > 2 else (2.0, 1.5)                  # sigma in pixels: IIR path
     img = W.synthetic_image(w, h, seed=11)
-    uv = {"hdev": 4.0 / max(w - 1, 1), "vdev": 3.0 / max(h - 1, 1)}     # sigma = 2 px and 1.5 px: IIR path
+    uv = {"hdev": 2 * sx / max(w - 1, 1), "vdev": 2 * sy / max(h - 1, 1)}
     flt = mm.Filter(W.GAUSS_DIRECT)
     inv = flt.invoke(w, h)
     for k, v in uv.items():
@@ -105,7 +116,12 @@ def test_gauss_iir_float_map_is_bit_exact(size):
     finally:
         lib().mmhip_device_free(C.c_void_p(dev))
     want = CpuFilter(flt.ir_json).render(w, h, uservals=uv, images={"in": img}, floatmap=True)
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    diff = got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)
+    if not segments or w * h < 100000:
+        assert not diff.any(), np.abs(got - want).max()
+    else:
+        assert np.abs(diff).max() <= 1 and np.count_nonzero(diff) <= max(2, 1e-5 * diff.size), \
+            (np.abs(diff).max(), np.count_nonzero(diff), diff.size)
 
 
 def test_gauss_row_stripes_with_local_halo_equal_full_frame():

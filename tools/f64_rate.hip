@@ -57,6 +57,10 @@ int main() {
     run<0, 2>("add ilp2", 1, out);
     run<0, 4>("add ilp4", 1, out);
     run<0, 1>("add dep", 8, out);
+    run<0, 1>("add dep", 2, out);
+    run<0, 1>("add dep", 4, out);
+    run<0, 2>("add ilp2", 2, out);
+    run<0, 2>("add ilp2", 4, out);
     run<0, 8>("add ilp8", 8, out);
     run<2, 8>("fma ilp8", 8, out);
     return 0;
