@@ -145,6 +145,34 @@ __device__ __forceinline__ double iir_step(double s0, double s1, double s2, doub
     return acc;
 }
 
+// The i = 0 term when more is known about the input s0:
+//  * causal, s0 never -0 (bytes / 255): n_p[0] = 1 / (sqrt(2 pi) sigma) > 0, so the product is -0 only for
+//    s0 = -0 and the addition to the +0 accumulator changes nothing else -- drop the addition;
+//  * anticausal, s0 finite: n_m[0] is +0 (find_iir_constants), the product is +-0 and the accumulator
+//    stays +0 -- drop the term.  (An infinite or NaN s0 would make it NaN: float-map inputs keep it.)
+template <bool S0_NOT_NEG_ZERO>
+__device__ __forceinline__ double iir_step_causal(double s0, double s1, double s2, double s3, double s4, double v1, double v2,
+                                                  double v3, double v4, const double *n, const double *d) {
+    if (!S0_NOT_NEG_ZERO) return iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, n, d);
+    double acc = n[0] * s0;
+    acc += n[1] * s1 - d[1] * v1;
+    acc += n[2] * s2 - d[2] * v2;
+    acc += n[3] * s3 - d[3] * v3;
+    acc += n[4] * s4 - d[4] * v4;
+    return acc;
+}
+template <bool S0_FINITE>
+__device__ __forceinline__ double iir_step_anticausal(double s0, double s1, double s2, double s3, double s4, double v1, double v2,
+                                                      double v3, double v4, const double *n, const double *d) {
+    if (!S0_FINITE) return iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, n, d);
+    double acc = 0.0;
+    acc += n[1] * s1 - d[1] * v1;
+    acc += n[2] * s2 - d[2] * v2;
+    acc += n[3] * s3 - d[3] * v3;
+    acc += n[4] * s4 - d[4] * v4;
+    return acc;
+}
+
 // steps 0..3 of a sweep (gauss.c:178-190: fewer than 4 predecessors, the rest uses the edge value)
 __device__ __forceinline__ double iir_edge_step(int j, double s0, double s1, double s2, double s3, double v1, double v2,
                                                 double v3, const double *n, const double *d, const double *bd,
@@ -168,8 +196,11 @@ __device__ __forceinline__ double iir_edge_step(int j, double s0, double s1, dou
 // base + 32-bit lane offset form.  row()/at() let a block of 16 consecutive k share one row address:
 // with a single wave on a SIMD every instruction, scalar ones included, takes an issue slot from
 // the recurrence, and per-element 64-bit index arithmetic was a third of a block's instructions.
-struct MapSrc {
+template <bool FINITE>
+struct MapSrcT {
     typedef float raw_t;
+    static constexpr bool not_neg_zero = false;    // a float map may hold -0 (so may a pass's own output: tiny negative sums round to it)
+    static constexpr bool finite = FINITE;         // the first pass's output when its input was a drawable
     const float *p;        // the map (uniform)
     unsigned stride;       // lines * 4
     unsigned lane;         // line * 4 + channel
@@ -179,14 +210,17 @@ struct MapSrc {
         return *(const raw_t *)((const char *)r + (((unsigned)u * stride + lane) << 2));
     }
     __device__ __forceinline__ float decode(raw_t v) const { return v; }
-    __device__ __forceinline__ MapSrc for_lane(long L) const { return MapSrc{p, stride, (unsigned)L}; }
+    __device__ __forceinline__ MapSrcT for_lane(long L) const { return MapSrcT{p, stride, (unsigned)L}; }
 };
+typedef MapSrcT<false> MapSrc;
+typedef MapSrcT<true> FiniteMapSrc;
 // ... or the input drawable itself when render_image's coordinate mapping (builtins.c:303-343)
 // is the identity -- a drawable of the render size, which the host establishes by evaluating
 // the mapping for every row and column (same float operations) before it picks this source.
 // render_image is then fused into the first pass: 4 instead of 16 B/px read, no 4.3 GB map.
 struct DrawableSrc {
     typedef uint32_t raw_t;
+    static constexpr bool not_neg_zero = true, finite = true;     // byte / 255
     const uint32_t *p;     // the drawable's window (uniform)
     unsigned sw;           // source pitch in pixels
     unsigned lane;         // column
@@ -249,7 +283,7 @@ __device__ __forceinline__ void causal_group(const Src &src, typename Src::raw_t
 #pragma unroll
                 for (int u = 0; u < IIR_U; ++u) {
                     const double s0v = (double)src.decode(cur[u]);
-                    const double acc = iir_step(s0v, s1_, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
+                    const double acc = iir_step_causal<Src::not_neg_zero>(s0v, s1_, s2, s3, s4, v1, v2, v3, v4, c.n_p, c.d_p);
                     s4 = s3; s3 = s2; s2 = s1_; s1_ = s0v;
                     v4 = v3; v3 = v2; v2 = v1; v1 = acc;
                 }
@@ -305,7 +339,7 @@ __device__ __forceinline__ void rerun_block(const Src &src, int b, int n, const 
     for (int u = 0; u < IIR_U; ++u) {
         if (!GUARD) {
             const double s0 = (double)src.decode(in[u]);
-            const double acc = iir_step(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
+            const double acc = iir_step_causal<Src::not_neg_zero>(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
             vc[u] = acc;
             cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
             cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
@@ -423,7 +457,7 @@ __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *_
             for (int u = 0; u < IIR_U; ++u) {
                 {
                     const double s0 = (double)src.decode(nxt.s[u]);
-                    const double acc = iir_step(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
+                    const double acc = iir_step_causal<Src::not_neg_zero>(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
                     nxt.vc[u] = acc;
                     cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
                     cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
@@ -431,7 +465,7 @@ __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *_
                 {
                     const int ua = IIR_U - 1 - u;
                     const double s0 = (double)src.decode(cur.s[ua]);
-                    const double acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
+                    const double acc = iir_step_anticausal<Src::finite>(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
                     tw[ll * (IIR_U * 4 + 4) + ua * 4 + ch] = (float)(cur.vc[ua] + acc);   // transfer_pixels, gauss.c:117-124
                     s4 = s3; s3 = s2; s2 = s1; s1 = s0;
                     v4 = v3; v3 = v2; v2 = v1; v1 = acc;
@@ -808,9 +842,15 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
     {
         const LineArgs g = plan_segments(w, hn, hs);
         const unsigned blocks = g.lane_blocks * segment_count(g);
-        const MapSrc src{mapT, (unsigned)hn * 4u, 0u};
-        k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-        k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c);
+        if (in.kind == IMG_FLOATMAP) {
+            const MapSrc src{mapT, (unsigned)hn * 4u, 0u};
+            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c);
+        } else {      // the first pass read bytes: its output is finite
+            const FiniteMapSrc src{mapT, (unsigned)hn * 4u, 0u};
+            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c);
+        }
     }
     if (hipGetLastError() != hipSuccess) { *err = "gaussian_blur: kernel launch failed"; return -1; }
     return 0;
