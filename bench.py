@@ -151,7 +151,7 @@ def main():
                        "jit_seconds": round(jit_s, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gaussian_blur chain: k_render_drawable + 2x(k_iir_causal, k_iir_anticausal_T) + mm_pixels"
+                         "kernel": "gaussian_blur chain: 2x(k_iir_causal, k_iir_anticausal_T), render_image fused into the first pass, the RGBA8 pack into the last"
                          if args.workload == "gauss" else "mm_pixels",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_pixel": bpp},
         }

@@ -128,6 +128,10 @@ double mmhip_last_kernel_ms(mmhip_invocation *inv);
 /* Durations of the pixel kernel of all timed launches since the last drain (oldest first, waits
    for the last one): lets a caller queue many launches without a synchronisation per launch. */
 int mmhip_drain_kernel_ms(mmhip_invocation *inv, double *out_ms, int cap);
+/* Launches of this invocation whose pixels a native filter wrote itself -- a filter like
+   examples/Blur/Gaussian Blur.mm, whose pixel is the blurred map sampled at the pixel centre: the
+   blur's last kernel packs the output (new_template.c.in:279-293) and the pixel kernel is skipped. */
+long mmhip_direct_native_launches(mmhip_invocation *inv);
 
 /* device memory helpers for callers without their own allocator */
 void *mmhip_device_alloc(size_t bytes);

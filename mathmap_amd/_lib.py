@@ -50,6 +50,7 @@ SYMBOLS = {
     "mmhip_set_color": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
     "mmhip_set_native_row_margin": (C.c_int, [C.c_void_p, C.c_int]),
     "mmhip_drain_kernel_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "mmhip_direct_native_launches": (C.c_long, [C.c_void_p]),
     "mmhip_set_curve": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmhip_set_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmhip_set_by_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),

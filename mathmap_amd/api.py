@@ -232,6 +232,10 @@ class Invocation:
             raise MathMapError(_err())
         return [buf[i] for i in range(n)]
 
+    def direct_native_launches(self):
+        """Launches whose pixels a native filter wrote itself (pixel kernel skipped)."""
+        return lib().mmhip_direct_native_launches(self._h)
+
     def render(self, t=0.0, frame=0):
         """Renders the whole frame and returns it as a uint8 [H,W,4] array (RGBA)."""
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)

@@ -462,8 +462,46 @@ struct Generator {
     std::vector<Value *> pro_defs, pix_defs;
     std::set<Value *> pro_uses, pix_uses;
 
+    // Follows plain copies (and phis-free assignments of a primary) to the defining statement.
+    static const Stmt *def_through_copies(const Primary &p) {
+        const Primary *q = &p;
+        for (int guard = 0; guard < 64; ++guard) {
+            if (q->kind != Primary::Val || !q->value->def) return nullptr;
+            const Stmt *d = q->value->def;
+            if (d->kind != Stmt::Assign) return nullptr;
+            if (d->rhs.kind == Rhs::Prim) { q = &d->rhs.prim; continue; }
+            return d;
+        }
+        return nullptr;
+    }
+    // The filter whose pixel is nothing but the result of native call k sampled at the pixel's own
+    // coordinates -- `soft = gaussian_blur(in, ...); soft(xy)`, examples/Blur/Gaussian Blur.mm.  The
+    // host may then let the native filter's last kernel write the output pixels itself (when the
+    // sample positions are the pixel centres, which it checks) and skip the pixel kernel.
+    int find_direct_native() const {
+        const Stmt *fetch = nullptr;
+        for (int i = 0; i < 4; ++i) {
+            if (!code.result[i]) return -1;
+            const Stmt *d = def_through_copies(Primary::V(code.result[i]));
+            if (!d || d->rhs.kind != Rhs::Op || strcmp(d->rhs.op->cname, "TUPLE_NTH") || d->rhs.args.size() != 2 ||
+                d->rhs.args[1].kind != Primary::IntConst || d->rhs.args[1].i != i)
+                return -1;
+            const Stmt *t = def_through_copies(d->rhs.args[0]);
+            if (!t || (fetch && t != fetch)) return -1;
+            fetch = t;
+        }
+        if (fetch->rhs.kind != Rhs::Op || strcmp(fetch->rhs.op->cname, "ORIG_VAL") || fetch->rhs.args.size() < 3) return -1;
+        const Stmt *dx = def_through_copies(fetch->rhs.args[0]), *dy = def_through_copies(fetch->rhs.args[1]);
+        if (!dx || dx->rhs.kind != Rhs::Internal || dx->rhs.internal != "x") return -1;
+        if (!dy || dy->rhs.kind != Rhs::Internal || dy->rhs.internal != "y") return -1;
+        const Stmt *img = def_through_copies(fetch->rhs.args[2]);
+        auto it = img ? native_index.find(img) : native_index.end();
+        return it == native_index.end() ? -1 : it->second;
+    }
+
     void analyze_and_layout() {
         find_natives(code.body);
+        ks.direct_native = find_direct_native();
         collect_values(code.body, PROLOGUE, pro_defs, pro_uses);
         collect_values(code.body, PIXEL, pix_defs, pix_uses);
         for (int i = 0; i < 4; ++i) pix_uses.insert(code.result[i]);

@@ -29,9 +29,23 @@ struct NativeWorkspace {
 // rows depend on a bounded neighbourhood of input rows (gaussian_blur: a halo of ceil(22.7 sigma)
 // rows, below which the recurrences' start-up error is under 1e-17 of the value) may fill only
 // those rows plus their halo; [0, render_h) asks for the whole map.
+// Optional direct output of a native filter (new_template.c.in:279-293 applied to the filter's own
+// result): when the calling filter's pixel is just this result sampled at the pixel centre, the
+// filter's last kernel also writes the RGBA8 pixels of rows [first_row, first_row + num_rows) x
+// columns [region_x, region_x + region_w) and the pixel kernel is not launched.  `written` reports
+// whether the path taken supports it (the recursive Gaussian does).
+struct NativeDirectOut {
+    void *out = nullptr;          // first requested row, first requested column
+    int row_stride = 0;           // bytes
+    int first_row = 0, num_rows = 0, region_x = 0, region_w = 0;
+    bool skip_map = false;        // in: the caller will not read the float map (it is not memoised): do not write it
+    bool written = false;         // out; with skip_map the map's contents are then undefined
+};
+
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
-                      std::string *err, int *row_lo, int *row_hi);   // in: rows wanted, out: rows filled
+                      std::string *err, int *row_lo, int *row_hi,    // in: rows wanted, out: rows filled
+                      NativeDirectOut *direct = nullptr);
 
 // native_fft.hip: convolve / half_convolve / visualize_fft (native-filters/convolve.c)
 int fft_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images, int render_w,

@@ -243,6 +243,20 @@ struct DrawableSrc {
 // The segment [s0, s1) of the line: the sweep starts at k0 = max(0, s0 - halo), at k0 > 0 as if k0
 // were the line's edge (see the segment note at k_iir_causal), and stores the checkpoints of the
 // segment's own blocks only.
+// Where the second pass also writes the packed output pixels (NativeDirectOut), in its own
+// coordinates: lines are rows of the window, steps are columns.
+struct PackOut { unsigned char *out; long row_stride; int line_lo, line_hi, k_lo, k_hi; int write_map; };
+
+// new_template.c.in:279-293 for output_bpp 4: CLAMP01 in float, the product in double, the
+// conversion to a byte truncates (mm_store_pixel in mm_device.h).
+__device__ __forceinline__ unsigned pack_rgba8(float4 v) {
+    const unsigned r = (unsigned char)(__builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f) * 255.0);
+    const unsigned g = (unsigned char)(__builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f) * 255.0);
+    const unsigned b = (unsigned char)(__builtin_amdgcn_fmed3f(v.z, 0.0f, 1.0f) * 255.0);
+    const unsigned a = (unsigned char)(__builtin_amdgcn_fmed3f(v.w, 0.0f, 1.0f) * 255.0);
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
 struct IirState { double s1, s2, s3, s4, v1, v2, v3, v4; };
 
 // IIR_PF + 1 consecutive blocks starting at kb0, ring slot j holding block kb0 + j*IIR_U.  A block's
@@ -368,7 +382,7 @@ template <class Src>
 __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *__restrict__ ck, unsigned stride, unsigned clane,
                                                  int n, int sg0, int sg1, int k1,
                                                  const IirCoef &c, float *tw, int lane, long line0, int lines,
-                                                 float *__restrict__ outT, bool active) {
+                                                 float *__restrict__ outT, const PackOut &po, bool active) {
     typedef typename Src::raw_t raw_t;
     const int ll = lane >> 2, ch = lane & 3;                // line within the wave's 16, channel
     const float initial_m = src.decode(src.fetch(k1 - 1)), initial_p = src.decode(src.fetch(0));
@@ -503,7 +517,9 @@ __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *_
             const int k = kb + kk;
             if (line < lines && (FAST || k < n)) {
                 const float4 v = *(const float4 *)&tw[tl * (IIR_U * 4 + 4) + kk * 4];
-                *(float4 *)&outT[(line * (long)n + k) * 4] = v;
+                if (po.write_map) *(float4 *)&outT[(line * (long)n + k) * 4] = v;
+                if (po.out && line >= po.line_lo && line < po.line_hi && k >= po.k_lo && k < po.k_hi)
+                    *(unsigned *)(po.out + (line - po.line_lo) * po.row_stride + (long)(k - po.k_lo) * 4) = pack_rgba8(v);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -547,7 +563,7 @@ __global__ void __launch_bounds__(256) k_iir_causal(Src in, double *__restrict__
 
 template <class Src>
 __global__ void __launch_bounds__(256) k_iir_anticausal_T(Src in, const double *__restrict__ ckpt, float *__restrict__ outT,
-                                                          LineArgs g, IirCoef c) {
+                                                          LineArgs g, IirCoef c, PackOut po) {
     // wave-private staging tile: 16 lines x IIR_U steps x 4 channels, line stride padded by 4 floats
     __shared__ float tile[4][16 * (IIR_U * 4 + 4)];
     const unsigned sgi = blockIdx.x / g.lane_blocks, lb = blockIdx.x % g.lane_blocks;
@@ -558,7 +574,7 @@ __global__ void __launch_bounds__(256) k_iir_anticausal_T(Src in, const double *
     const bool active = L < stride;
     const long Lc = active ? L : 0;      // idle lanes of the last wave shadow lane 0; their tile rows are never written out
     const int s0 = (int)sgi * g.seg, s1 = min(g.n, s0 + g.seg), k1 = s1 < g.n ? min(g.n, s1 + g.halo) : g.n;
-    anticausal_sweep(in.for_lane(Lc), ckpt, (unsigned)stride, (unsigned)Lc, g.n, s0, s1, k1, c, tile[wave], lane, line0, g.lines, outT, active);
+    anticausal_sweep(in.for_lane(Lc), ckpt, (unsigned)stride, (unsigned)Lc, g.n, s0, s1, k1, c, tile[wave], lane, line0, g.lines, outT, po, active);
 }
 
 // How to split lines of n steps, `lines` of them, for a recurrence of standard deviation sigma.
@@ -726,7 +742,7 @@ int gauss_rle(float *map, float *tmp, int w, int h, float hs, float vs, NativeWo
 }
 
 int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, int rw, int rh, float *out_map,
-                  NativeWorkspace &ws, hipStream_t s, std::string *err, int *rows_lo, int *rows_hi) {
+                  NativeWorkspace &ws, hipStream_t s, std::string *err, int *rows_lo, int *rows_hi, NativeDirectOut *direct) {
     const int row_lo = *rows_lo, row_hi = *rows_hi;
     *rows_lo = 0;             // paths that fill the whole map leave it so; the windowed IIR path narrows it
     *rows_hi = rh;
@@ -829,11 +845,11 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         if (in.kind == IMG_FLOATMAP || !identity) {
             const MapSrc src{(in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map) + (long)y0 * w * 4, (unsigned)w * 4u, 0u};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1});
         } else {
             const DrawableSrc src{(const uint32_t *)in.data + (long)y0 * in.w, (unsigned)in.w, 0u, 0};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1});
         }
     }
     // horizontal pass (gauss.c:203-252): in mapT the window's rows are the "columns"; transposing again
@@ -842,14 +858,22 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
     {
         const LineArgs g = plan_segments(w, hn, hs);
         const unsigned blocks = g.lane_blocks * segment_count(g);
+        // lines of this pass are rows of the window [y0, y1), steps are columns
+        PackOut po{nullptr, 0, 0, 0, 0, 0, 1};
+        if (direct && direct->out && direct->first_row >= y0 && direct->first_row + direct->num_rows <= y1) {
+            po = PackOut{(unsigned char *)direct->out, (long)direct->row_stride, direct->first_row - y0,
+                         direct->first_row + direct->num_rows - y0, direct->region_x, direct->region_x + direct->region_w,
+                         direct->skip_map ? 0 : 1};
+            direct->written = true;
+        }
         if (in.kind == IMG_FLOATMAP) {
             const MapSrc src{mapT, (unsigned)hn * 4u, 0u};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po);
         } else {      // the first pass read bytes: its output is finite
             const FiniteMapSrc src{mapT, (unsigned)hn * 4u, 0u};
             k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c);
+            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po);
         }
     }
     if (hipGetLastError() != hipSuccess) { *err = "gaussian_blur: kernel launch failed"; return -1; }
@@ -905,9 +929,9 @@ void launch_supersample_combine(const unsigned char *longs, const unsigned char 
 
 int run_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images,
                       int render_w, int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream,
-                      std::string *err, int *row_lo, int *row_hi) {
+                      std::string *err, int *row_lo, int *row_hi, NativeDirectOut *direct) {
     if (func == "native_filter_gaussian_blur")
-        return gaussian_blur(rec, images, render_w, render_h, out_map, ws, stream, err, row_lo, row_hi);
+        return gaussian_blur(rec, images, render_w, render_h, out_map, ws, stream, err, row_lo, row_hi, direct);
     *row_lo = 0;              // every other native filter produces the whole map
     *row_hi = render_h;
     if (func == "RENDER") {   // render_image (builtins.c:267-346), drawable / float-map branches

@@ -306,6 +306,8 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
     inv->native_maps.assign(f->ks.natives.size(), nullptr);
     inv->native_memo.resize(f->ks.natives.size());
     inv->native_memo_gen.assign(f->ks.natives.size(), 0);
+    inv->native_seen.resize(f->ks.natives.size());
+    inv->native_seen_gen.assign(f->ks.natives.size(), ~0ULL);
     inv->native_rows.assign(f->ks.natives.size(), {0, 0});
     if (inv->images.empty()) { HImageDesc d{}; d.kind = IMG_NULL; inv->images.push_back(d); }
     auto bail = [&](const char *what, hipError_t e) -> mmhip_invocation * {
@@ -510,6 +512,8 @@ static int next_event_pair(mmhip_invocation *inv) {
 
 // Durations (ms) of the pixel kernel of every timed launch since the last drain, oldest first;
 // waits for the last of them.  Returns how many were written (at most `cap`).
+long mmhip_direct_native_launches(mmhip_invocation *inv) { return inv->direct_native_launches; }
+
 int mmhip_drain_kernel_ms(mmhip_invocation *inv, double *out_ms, int cap) {
     int n = 0;
     if (inv->ev_used > 0 && hipEventSynchronize(inv->ev_pool[inv->ev_used - 1].second) != hipSuccess) return fail("event sync failed");
@@ -544,11 +548,39 @@ static int upload_tables(mmhip_invocation *inv, hipStream_t s) {
     return 0;
 }
 
-static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
-    mmhip_filter *f = inv->f;
+static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, hipStream_t s, bool *direct_written) {
     std::vector<char> host(f->ks.xy_bytes);
     HIP_TRY(hipMemcpyAsync(host.data(), inv->d_xy, host.size(), hipMemcpyDeviceToHost, s));
+    // Direct output (hipgen.cpp find_direct_native): the pixel is native result k sampled at (x, y).
+    // If every sample position of this launch is the pixel's own centre -- get_floatmap_pixel's
+    // lrintf(ax x + bx) (builtins.c:247-265) evaluated here for each column and row with the
+    // coordinates the prologue just computed -- the native filter may write the RGBA8 pixels itself.
+    NativeDirectOut direct;
+    const bool try_direct = f->ks.direct_native >= 0 && !a.floatmap && a.output_bpp == 4 && (a.row_stride & 3) == 0 &&
+                            ((uintptr_t)a.out & 3) == 0 && !getenv("MMHIP_NO_DIRECT_NATIVE");
+    std::vector<float> xt, yt;
+    if (try_direct) {
+        xt.resize(a.region_width);
+        yt.resize(a.num_rows);
+        HIP_TRY(hipMemcpyAsync(xt.data(), a.xtab, xt.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(yt.data(), a.ytab, yt.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
+    if (try_direct) {
+        const float ax = (float)((float)(a.render_width - 1) / 2.0), bx = ax;       // floatmap.c:39-41
+        const float by = (float)((float)(a.render_height - 1) / 2.0), ay = by * -1.0f;
+        bool identity = true;
+        for (int c = 0; c < a.region_width && identity; ++c) identity = lrintf(ax * xt[c] + bx) == (long)a.region_x + c;
+        for (int r = 0; r < a.num_rows && identity; ++r) identity = lrintf(ay * yt[r] + by) == (long)a.first_row + r;
+        if (identity) {
+            direct.out = a.out;
+            direct.row_stride = a.row_stride;
+            direct.first_row = a.first_row;
+            direct.num_rows = a.num_rows;
+            direct.region_x = a.region_x;
+            direct.region_w = a.region_width;
+        }
+    }
     bool table_changed = false;
     for (size_t k = 0; k < f->ks.natives.size(); ++k) {
         HNativeRec rec;
@@ -572,9 +604,28 @@ static int run_natives(mmhip_invocation *inv, const HArgs &a, hipStream_t s) {
         if (!inv->native_maps[k]) HIP_TRY(hipMalloc(&inv->native_maps[k], bytes));
         std::string err;
         int got_lo = want_lo, got_hi = want_hi;
+        NativeDirectOut *dk = (direct.out && (int)k == f->ks.direct_native) ? &direct : nullptr;
+        // A launch that covers the whole frame needs the map for nothing but the memo.  The first time
+        // an argument set is seen it is therefore not written (16 of the second pass's 20 B/px); a
+        // second request for the same set -- an animation that keeps the blur's arguments -- computes
+        // it once more, with the map, and is memoised from then on.
+        const bool whole = a.region_x == 0 && a.region_y == 0 && a.region_width == a.render_width &&
+                           a.region_height == a.render_height && a.first_row == 0 && a.num_rows == a.render_height;
+        if (dk) {
+            dk->skip_map = whole && !(inv->native_seen_gen[k] == inv->input_generation &&
+                                      memcmp(&inv->native_seen[k], &rec, sizeof rec) == 0);
+            inv->native_seen[k] = rec;
+            inv->native_seen_gen[k] = inv->input_generation;
+        }
         int rc = run_native_filter(f->ks.natives[k].func, rec, inv->images, a.render_width, a.render_height,
-                                   (float *)inv->native_maps[k], inv->ws, s, &err, &got_lo, &got_hi);
+                                   (float *)inv->native_maps[k], inv->ws, s, &err, &got_lo, &got_hi, dk);
         if (rc != 0) return fail(err);
+        if (dk && dk->written) *direct_written = true;
+        if (dk && dk->written && dk->skip_map) {       // nothing to memoise, no map to describe
+            inv->native_memo_gen[k] = ~0ULL;
+            inv->native_rows[k] = {0, 0};
+            continue;
+        }
         HImageDesc &d = inv->images[slot];
         d.data = inv->native_maps[k];
         d.w = a.render_width;
@@ -739,6 +790,7 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     }
     char *xy = inv->d_xy;
     void *params[] = {&a, &xy};
+    bool direct_written = false;      // a native filter wrote this launch's pixels itself (run_natives)
     {
         // The prologue's outputs (frame constants, coordinate tables) depend on the filter, the
         // geometry, the user values / image table and -- only if its code reads them -- t and
@@ -754,7 +806,7 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
         if (!fresh) {
             int n = std::max(region_w, a.num_rows);
             HIP_TRY(hipModuleLaunchKernel(f->f_pro, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
-            if (!f->ks.natives.empty() && run_natives(inv, a, s) != 0) return -1;
+            if (!f->ks.natives.empty() && run_natives(inv, f, a, s, &direct_written) != 0) return -1;
             inv->pro_args = key;
             inv->pro_filter = f;
             inv->pro_stream = (void *)s;
@@ -778,7 +830,8 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
         if (next_event_pair(inv) != 0) return -1;
         HIP_TRY(hipEventRecord(inv->ev0, s));
     }
-    HIP_TRY(hipModuleLaunchKernel(f->f_pix, (unsigned)nwg, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+    if (direct_written) ++inv->direct_native_launches;
+    if (!direct_written) HIP_TRY(hipModuleLaunchKernel(f->f_pix, (unsigned)nwg, 1, 1, 256, 1, 1, 0, s, params, nullptr));
     if (inv->timing) {
         HIP_TRY(hipEventRecord(inv->ev1, s));
         inv->ev_valid = true;

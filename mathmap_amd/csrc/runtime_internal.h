@@ -60,8 +60,11 @@ struct mmhip_invocation {
     std::vector<void *> native_maps;       // float4 maps produced by native filters
     std::vector<mm::HNativeRec> native_memo;   // args of the call that produced native_maps[k]
     std::vector<unsigned long long> native_memo_gen;
+    std::vector<mm::HNativeRec> native_seen;   // last argument set whose map was asked for (direct output: materialised on its second use)
+    std::vector<unsigned long long> native_seen_gen;
     std::vector<std::pair<int, int>> native_rows;   // rows of native_maps[k] that are valid
     int native_row_margin = -1;                     // mmhip_set_native_row_margin
+    long direct_native_launches = 0;                // mmhip_direct_native_launches
     // the prologue kernel is skipped while nothing it reads has changed (mmhip_render)
     mm::HArgs pro_args{};
     const mmhip_filter *pro_filter = nullptr;

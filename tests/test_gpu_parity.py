@@ -124,6 +124,74 @@ def test_gauss_iir_float_map_is_bit_exact(size, segments, monkeypatch):
             (np.abs(diff).max(), np.count_nonzero(diff), diff.size)
 
 
+@pytest.mark.parametrize("size,sig", [((300, 200), (3.0, 2.5)), ((129, 65), (2.0, 1.5)), ((1037, 650), (11.0, 7.5))])
+def test_gauss_direct_output_equals_pixel_kernel(size, sig, monkeypatch):
+    """`soft = gaussian_blur(in, ..); soft(xy)`: the blur's second pass packs the RGBA8 pixels itself and
+    the pixel kernel is skipped (hipgen find_direct_native, runtime run_natives).  Same bytes as the
+    pixel kernel sampling the float map, and as the oracle.  A whole-frame launch does not even write
+    the map the first time an argument set is seen; the second identical frame computes it (and still
+    writes the pixels directly), the third is a memo hit and goes through the pixel kernel.  Row
+    bands and a region that does not start at column 0 exercise the memo and the offsets of the
+    direct write."""
+    import ctypes as C
+    from mathmap_amd._lib import lib
+    w, h = size
+    img = W.synthetic_image(w, h, seed=21)
+    uv = {"hdev": 2 * sig[0] / (w - 1), "vdev": 2 * sig[1] / (h - 1)}
+
+    def make():
+        flt = mm.Filter(W.GAUSS_DIRECT)
+        inv = flt.invoke(w, h)
+        for k, v in uv.items():
+            inv.set(k, v)
+        inv.set_image("in", img)
+        return flt, inv
+
+    def device_render(inv, rows, region=None):
+        rx, ry, rw, rh = region or (0, 0, w, h)
+        dev = lib().mmhip_device_alloc(rw * rh * 4)
+        try:
+            for lo, hi in rows:
+                inv.render_rows(dev + (lo - ry) * rw * 4, lo, hi, region=region)
+            inv.sync()
+            out = np.empty((rh, rw, 4), np.uint8)
+            assert lib().mmhip_copy_to_host(out.ctypes.data_as(C.c_void_p), C.c_void_p(dev), rw * rh * 4) == 0
+        finally:
+            lib().mmhip_device_free(C.c_void_p(dev))
+        return out
+
+    monkeypatch.delenv("MMHIP_NO_DIRECT_NATIVE", raising=False)
+    flt, inv = make()
+    got = inv.render()                                     # direct, map not written
+    assert inv.direct_native_launches() == 1
+    second = inv.render()                                  # same arguments again: direct, map written and memoised
+    assert inv.direct_native_launches() == 2
+    third = inv.render()                                   # memo hit: pixel kernel on the memoised map
+    assert inv.direct_native_launches() == 2
+    assert np.array_equal(got, second) and np.array_equal(got, third)
+    want = CpuFilter(flt.ir_json).render(w, h, uservals=uv, images={"in": img})
+    assert np.array_equal(got, want), stats(got, want)
+
+    monkeypatch.setenv("MMHIP_NO_DIRECT_NATIVE", "1")
+    _, inv2 = make()
+    plain = inv2.render()
+    assert inv2.direct_native_launches() == 0
+    assert np.array_equal(got, plain)
+
+    monkeypatch.delenv("MMHIP_NO_DIRECT_NATIVE")
+    _, inv3 = make()
+    cut = h // 3 + 1
+    banded = device_render(inv3, [(0, cut), (cut, h)])     # band 1: map + direct rows; band 2: memo hit, pixel kernel
+    assert inv3.direct_native_launches() == 1
+    assert np.array_equal(banded, got)
+
+    _, inv4 = make()                                       # a region inside the frame: direct write with offsets
+    rx, ry, rw, rh = 16, 5, w - 40, h - 9
+    reg = device_render(inv4, [(ry, ry + rh)], region=(rx, ry, rw, rh))
+    assert inv4.direct_native_launches() == 1
+    assert np.array_equal(reg, got[ry:ry + rh, rx:rx + rw])
+
+
 def test_gauss_row_stripes_with_local_halo_equal_full_frame():
     """Multi-GPU striping of a blurred frame: each stripe's render fills only its rows
     of the blur map plus a halo of ceil(22.7 sigma) rows computed locally from the replicated
