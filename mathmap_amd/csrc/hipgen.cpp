@@ -411,14 +411,56 @@ struct Generator {
         out << ind << "}\n";
     }
 
+    // sin(v) and cos(v) of the same float value in one block (toXY of an `ra` filter): evaluated
+    // together by mmf_sincos_f32 -- one argument reduction -- at the first of the two statements.
+    static bool is_fast_sincos(const Stmt *s, bool *is_sin) {
+        if (s->kind != Stmt::Assign || s->rhs.kind != Rhs::Op || s->rhs.args.size() != 1) return false;
+        const char *cn = s->rhs.op->cname;
+        if (strcmp(cn, "sin") && strcmp(cn, "cos")) return false;
+        if (!s->lhs || s->lhs->var->type != Ty::Float || s->rhs.args[0].type() != Ty::Float || s->rhs.args[0].kind != Primary::Val)
+            return false;
+        *is_sin = !strcmp(cn, "sin");
+        return true;
+    }
+    struct SinCosRole { int id; bool first; };
+    std::map<const Stmt *, SinCosRole> sincos_role;
+    std::set<const Block *> sincos_scanned;
+    int sincos_ids = 0;
+    void pair_sincos(Block &b, Slice sl) {
+        for (size_t i = 0; i < b.size(); ++i) {
+            bool sin_i, sin_j;
+            Stmt *si = b[i];
+            if (!(sl == PROLOGUE ? si->hoisted : si->in_pixel) || sincos_role.count(si) || !is_fast_sincos(si, &sin_i)) continue;
+            for (size_t j = i + 1; j < b.size(); ++j) {
+                Stmt *sj = b[j];
+                if (!(sl == PROLOGUE ? sj->hoisted : sj->in_pixel) || sincos_role.count(sj) || !is_fast_sincos(sj, &sin_j)) continue;
+                if (sin_j == sin_i || sj->rhs.args[0].value != si->rhs.args[0].value) continue;
+                sincos_role[si] = SinCosRole{sincos_ids, true};
+                sincos_role[sj] = SinCosRole{sincos_ids, false};
+                ++sincos_ids;
+                break;
+            }
+        }
+    }
+
     void stmts(Block &b, Slice sl, const std::string &ind) {
+        if (opt.fast_math_exact && sl == PIXEL && sincos_scanned.insert(&b).second) pair_sincos(b, sl);
         for (Stmt *s : b) {
             bool mine = sl == PROLOGUE ? s->hoisted : s->in_pixel;
             if (!mine) continue;
             switch (s->kind) {
-                case Stmt::Assign:
+                case Stmt::Assign: {
+                    auto sc = sl == PIXEL ? sincos_role.find(s) : sincos_role.end();
+                    if (sc != sincos_role.end()) {
+                        const std::string t = "mm_sc" + std::to_string(sc->second.id);
+                        if (sc->second.first)
+                            out << ind << "const mmf_sincos_t " << t << " = mmf_sincos_f32(" << prim(s->rhs.args[0], sl) << ");\n";
+                        out << ind << vname(s->lhs) << " = " << t << (!strcmp(s->rhs.op->cname, "sin") ? ".s" : ".c") << ";\n";
+                        break;
+                    }
                     out << ind << vname(s->lhs) << " = " << rhs(s->rhs, sl, s, s->lhs->var) << ";\n";
                     break;
+                }
                 case Stmt::If:
                     out << ind << "if (" << rhs(s->cond, sl, s, nullptr) << ") {\n";
                     stmts(s->then_, sl, ind + "  ");

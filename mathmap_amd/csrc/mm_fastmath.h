@@ -82,6 +82,26 @@ MMF_FN float mmf_cos_f32(float x) {
     return (float)r;
 }
 
+// sin and cos of the same argument (the polar -> cartesian conversion of every `ra` filter): one
+// reduction, the same operations per result as the two functions above -- identical values.
+typedef struct { float s, c; } mmf_sincos_t;
+MMF_FN mmf_sincos_t mmf_sincos_f32(float x) {
+    mmf_sincos_t o;
+    if (!(MMF_FABSF(x) < MMF_LIMIT)) {
+        o.s = (float)MMF_SIN_SLOW((double)x);
+        o.c = (float)MMF_COS_SLOW((double)x);
+        return o;
+    }
+    double sy, cm1;
+    const int k = mmf_reduce((double)x, &sy, &cm1) & 63;
+    const double s = mmf_sincos_table[2 * k], c = mmf_sincos_table[2 * k + 1];
+    const double rs = s + MMF_FMA(s, cm1, c * sy);
+    const double rc = c + MMF_FMA(c, cm1, -(s * sy));
+    o.s = x == 0.0f ? x : (float)rs;
+    o.c = (float)rc;
+    return o;
+}
+
 // Both, in double, for the float-complex functions (which evaluate in double and round once):
 // the same reduction, accurate to about half an ulp of double for any |xd| < MMF_LIMIT.
 MMF_FN void mmf_sincos_d(double xd, double *sn, double *cs) {

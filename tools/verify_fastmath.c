@@ -41,6 +41,9 @@ static void *worker(void *p) {
             const float x = float_of((uint32_t)u | ((uint32_t)sign << 31));
             const float ws = (float)sin((double)x), wc = (float)cos((double)x);
             const float gs = mmf_sin_f32(x), gc = mmf_cos_f32(x);
+            const mmf_sincos_t both = mmf_sincos_f32(x);         /* the fused pair must be the same two values */
+            if (bits_of(both.s) != bits_of(gs)) ++a->bad_sin;
+            if (bits_of(both.c) != bits_of(gc)) ++a->bad_cos;
             if (bits_of(ws) != bits_of(gs)) { if (!a->bad_sin && !a->bad_cos) a->first_bad = bits_of(x); ++a->bad_sin; }
             if (bits_of(wc) != bits_of(gc)) { if (!a->bad_sin && !a->bad_cos) a->first_bad = bits_of(x); ++a->bad_cos; }
             ++a->checked;
