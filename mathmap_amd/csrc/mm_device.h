@@ -177,6 +177,16 @@ MM_DEV mm_tup<3> mm_ell_jac(double u, double m) {
 #define SOLVE_LINEAR_2(m, v) (mm_solve_linear_2((m), (v)))
 #define SOLVE_LINEAR_3(m, v) (mm_solve_linear_3((m), (v)))
 #define ELL_JAC(u, m) (mm_ell_jac((u), (m)))
+#define ELL_INT_K_COMP(k) (mmg_ellint_Kcomp((k)))
+#define ELL_INT_E_COMP(k) (mmg_ellint_Ecomp((k)))
+#define ELL_INT_F(phi, k) (mmg_ellint_F((phi), (k)))
+#define ELL_INT_E(phi, k) (mmg_ellint_E((phi), (k)))
+#define ELL_INT_P(phi, k, n) (mmg_ellint_P((phi), (k), (n)))
+#define ELL_INT_D(phi, k, n) (mmg_ellint_D((phi), (k)))      /* GSL >= 2: no n (opmacros.h:108-112) */
+#define ELL_INT_RC(x, y) (mmg_ellint_RC((x), (y)))
+#define ELL_INT_RD(x, y, z) (mmg_ellint_RD((x), (y), (z)))
+#define ELL_INT_RF(x, y, z) (mmg_ellint_RF((x), (y), (z)))
+#define ELL_INT_RJ(x, y, z, p) (mmg_ellint_RJ((x), (y), (z), (p)))
 // g_random_double_range(a, b): u * (b - a) + a in double.  `col`, `rl`, `mm_rand_ctr` are the pixel
 // kernel's locals: absolute pixel position, so the value does not depend on stripes or tiles.
 #define RAND(a, b) \

@@ -32,10 +32,7 @@ BUILD = os.path.join(HERE, "_build")
 CTYPES = {"int": "int", "float": "float", "complex": "float _Complex", "color": "color_t",
           "curve": "int", "gradient": "int", "image": "mmo_image"}
 
-UNSUPPORTED = {"ELL_INT_K_COMP", "ELL_INT_E_COMP", "ELL_INT_F", "ELL_INT_E", "ELL_INT_P", "ELL_INT_D",
-               "ELL_INT_RC", "ELL_INT_RD", "ELL_INT_RF", "ELL_INT_RJ",
-               "SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH",
-               }
+UNSUPPORTED = {"SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH"}
 NOISE_OPS = {"libnoise_perlin", "libnoise_billow", "libnoise_ridged_multi", "libnoise_voronoi"}
 NOISE_LIB = os.path.join(HERE, "_ref", "libmmnoise.so")
 

@@ -216,6 +216,16 @@ static inline mmo_tup3 mmo_ell_jac(double u, double m) {
 #define SOLVE_LINEAR_2(m, v) (mmo_solve_linear_2((m), (v)))
 #define SOLVE_LINEAR_3(m, v) (mmo_solve_linear_3((m), (v)))
 #define ELL_JAC(u, m) (mmo_ell_jac((u), (m)))
+#define ELL_INT_K_COMP(k) (mmg_ellint_Kcomp((k)))
+#define ELL_INT_E_COMP(k) (mmg_ellint_Ecomp((k)))
+#define ELL_INT_F(phi, k) (mmg_ellint_F((phi), (k)))
+#define ELL_INT_E(phi, k) (mmg_ellint_E((phi), (k)))
+#define ELL_INT_P(phi, k, n) (mmg_ellint_P((phi), (k), (n)))
+#define ELL_INT_D(phi, k, n) (mmg_ellint_D((phi), (k)))
+#define ELL_INT_RC(x, y) (mmg_ellint_RC((x), (y)))
+#define ELL_INT_RD(x, y, z) (mmg_ellint_RD((x), (y), (z)))
+#define ELL_INT_RF(x, y, z) (mmg_ellint_RF((x), (y), (z)))
+#define ELL_INT_RJ(x, y, z, p) (mmg_ellint_RJ((x), (y), (z), (p)))
 #define RAND(a, b) \
     (mmg_rand_unit(col + A->region_x, row + A->region_y, A->frame, mm_rand_ctr++) * ((double)(b) - (double)(a)) + (double)(a))
 #define gsl_sf_beta(a, b) (exp(lgamma((a)) + lgamma((b)) - lgamma((a) + (b))))   /* GSL absent: parity unpinned */

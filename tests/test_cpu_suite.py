@@ -458,3 +458,39 @@ int main(int argc, char **argv) {
         out = subprocess.run(args, stdout=subprocess.PIPE, text=True, check=True).stdout.split()
     assert abs(float(out[0]) - 1.172396) < 2e-6 and abs(float(out[1]) - 0.436507) < 2e-6
     assert int(out[2]) == 0
+
+
+def test_elliptic_integrals_against_scipy():
+    """ELL_INT_* (mm_gslmath.h, restated gsl_sf_ellint_* with GSL_PREC_SINGLE): the oracle build against
+    scipy's Legendre and Carlson integrals on a square frame (x, y in [-1, 1]); P and D, which scipy
+    lacks in this form, against quadrature.  GSL itself is absent: this pins the mathematics, not GSL's
+    last bits."""
+    import scipy.special as sp
+    from scipy.integrate import quad
+    n = 48
+
+    def run(expr):
+        flt = mm.Filter("filter e () v = %s; rgba:[v, v * 0.5, 0, 1] end" % expr)
+        return CpuFilter(flt.ir_json).render(n, n, floatmap=True)[..., 0].astype(np.float64)
+
+    c = ((np.arange(n) - (n - 1) / 2.0) / ((n - 1) / 2.0)).astype(np.float32)
+    X, Y = np.meshgrid(c.astype(np.float64), (-c).astype(np.float64))
+    k = (X.astype(np.float32) * np.float32(0.9)).astype(np.float64)
+    phi = (Y.astype(np.float32) * np.float32(4)).astype(np.float64)
+    cases = [("ell_int_Kcomp(x * 0.9)", sp.ellipk(k * k)), ("ell_int_Ecomp(x * 0.9)", sp.ellipe(k * k)),
+             ("ell_int_F(y * 4, x * 0.9)", sp.ellipkinc(phi, k * k)), ("ell_int_E(y * 4, x * 0.9)", sp.ellipeinc(phi, k * k)),
+             ("ell_int_RC(x + 1.5, y + 1.2)", sp.elliprc(X + 1.5, Y + 1.2)),
+             ("ell_int_RD(x + 1.5, y + 1.2, 0.7)", sp.elliprd(X + 1.5, Y + 1.2, 0.7)),
+             ("ell_int_RF(x + 1.5, y + 1.2, 0.7)", sp.elliprf(X + 1.5, Y + 1.2, 0.7)),
+             ("ell_int_RJ(x + 1.5, y + 1.2, 0.7, 2.5)", sp.elliprj(X + 1.5, Y + 1.2, 0.7, 2.5))]
+    for expr, want in cases:
+        got = run(expr)
+        assert np.max(np.abs(got - want) / np.abs(want)) < 5e-7, expr
+    gp, gd = run("ell_int_P(y * 4, x * 0.9, 0.3)"), run("ell_int_D(y * 4, x * 0.9, 0)")
+    for i in range(0, n, 7):
+        for j in range(0, n, 5):
+            p, kk = phi[i, j], k[i, j]
+            wp = quad(lambda t: 1 / ((1 + 0.3 * np.sin(t) ** 2) * np.sqrt(1 - kk * kk * np.sin(t) ** 2)), 0, p)[0]
+            wd = quad(lambda t: np.sin(t) ** 2 / np.sqrt(1 - kk * kk * np.sin(t) ** 2), 0, p)[0]
+            assert abs(gp[i, j] - wp) <= 5e-7 * abs(wp) + 1e-9 and abs(gd[i, j] - wd) <= 5e-7 * abs(wd) + 1e-9, (i, j)
+    assert np.isnan(run("ell_int_Kcomp(1.5 + x * 0)")).all()           # k^2 >= 1: domain error

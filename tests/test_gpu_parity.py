@@ -632,12 +632,19 @@ GSL_PROBES = [
     # gsl_sf_elljac_e (opmacros.h:118-126), real and complex argument
     ("rgba:[ell_jac_sn(x * 3, 0.5), ell_jac_cn(y * 3, 0.3), ell_jac_dn(x * y * 4, 0.8), ell_jac_sn(x, 1.5)]", 4),
     ("w = ell_jac_cn(ri:[x * 2, y * 2], 0.5); rgba:[w[0], w[1], w[0], w[1]]", 16),
+    # gsl_sf_ellint_* (opmacros.h:102-117): complete, Legendre (phi beyond pi/2: the periodic terms) and Carlson
+    # forms, domain errors (k^2 >= 1, negative arguments) as NaN
+    ("rgba:[ell_int_Kcomp(x * 0.99), ell_int_Ecomp(y * 0.99), ell_int_Kcomp(x * 1.2), ell_int_Ecomp(0.99999999)]", 4),
+    ("rgba:[ell_int_F(y * 4, x * 0.9), ell_int_E(y * 4, x * 0.9), ell_int_P(y * 4, x * 0.9, 0.3), ell_int_D(y * 4, x * 0.9, 0)]", 8),
+    ("rgba:[ell_int_RC(x + 1.2, y + 1.1), ell_int_RD(x + 1.2, y + 1.1, 0.7), ell_int_RF(x + 1.2, y + 1.1, 0.7), "
+     "ell_int_RJ(x + 1.2, y + 1.1, 0.7, 2.5)]", 4),
+    ("rgba:[ell_int_RC(x, y), ell_int_RF(x, y, x * y), ell_int_RD(x + 1, y, 0.5), ell_int_RJ(x + 1, y + 1, 1, x)]", 8),
 ]
 
 
 @pytest.mark.parametrize("body,max_ulp", GSL_PROBES)
 def test_gsl_operators_match_restatement(body, max_ulp):
-    """SOLVE_LINEAR_2/3 and ELL_JAC: device vs the oracle build of the same restated GSL algorithms
+    """SOLVE_LINEAR_2/3, ELL_JAC and ELL_INT_*: device vs the oracle build of the same restated GSL algorithms
     (mm_gslmath.h; GSL itself is absent -- parity with the reference is unpinned).  Float-map
     output; differences come from OCML vs glibc sqrt/sin/cos/hypot inside the algorithms."""
     import ctypes as C
