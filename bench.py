@@ -51,6 +51,7 @@ def main():
 
     import mathmap_amd as mm
     from mathmap_amd import workloads as W
+    mm.set_device(local_rank)                  # the library's own handle on the rank's GPU (one process per GPU)
 
     w = h = args.size or (16384 if args.workload == "gauss" else 8192)
     src = W.ALL["gauss_direct" if args.workload == "gauss" else args.workload]

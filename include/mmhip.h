@@ -139,6 +139,10 @@ void mmhip_device_free(void *p);
 int mmhip_copy_to_host(void *dst_host, const void *src_device, size_t bytes);
 int mmhip_copy_to_device(void *dst_device, const void *src_host, size_t bytes);
 int mmhip_device_count(void);
+/* One process per GPU: selects the device (ordinal among the visible ones) the calling thread's later
+   mmhip_* calls use -- invocations, their streams, modules and buffers live on the device that is
+   current when they are created.  Returns 0, or -1 with mmhip_last_error(). */
+int mmhip_set_device(int ordinal);
 
 #ifdef __cplusplus
 }

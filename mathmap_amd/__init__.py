@@ -6,4 +6,4 @@ runtime, hand-written HIP kernels behind the C ABI of include/mmhip.h),
 (the benchmark filters), ``striping.py`` (row stripes across GPUs).
 """
 from .api import (EDGE_COLOR, EDGE_REFLECT, EDGE_ROTATE, EDGE_WRAP, Filter, Invocation, MathMapError,  # noqa: F401
-                  device_count)
+                  device_count, set_device)

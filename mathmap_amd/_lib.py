@@ -72,6 +72,7 @@ SYMBOLS = {
     "mmhip_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mmhip_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mmhip_device_count": (C.c_int, []),
+    "mmhip_set_device": (C.c_int, [C.c_int]),
 }
 
 # reference-ABI tier (include/mathmap_hip_backend.h) and its self-test driver

@@ -263,3 +263,9 @@ class Invocation:
 
 def device_count():
     return lib().mmhip_device_count()
+
+
+def set_device(ordinal):
+    """One process per GPU: the device later invocations of this thread are created on."""
+    if lib().mmhip_set_device(int(ordinal)) != 0:
+        raise MathMapError(_err())

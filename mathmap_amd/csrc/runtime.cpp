@@ -901,6 +901,10 @@ int mmhip_copy_to_device(void *dst, const void *src, size_t bytes) {
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
+int mmhip_set_device(int ordinal) {
+    HIP_TRY(hipSetDevice(ordinal));
+    return 0;
+}
 int mmhip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
