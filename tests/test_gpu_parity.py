@@ -185,6 +185,23 @@ def test_gauss_direct_output_equals_pixel_kernel(size, sig, monkeypatch):
     assert inv3.direct_native_launches() == 1
     assert np.array_equal(banded, got)
 
+    # one invocation per stripe, each asking the blur for its own rows only (the multi-GPU stripe mode):
+    # every stripe computes its window + halo and writes its rows directly
+    dev = lib().mmhip_device_alloc(w * h * 4)
+    try:
+        bounds = [0, h // 3, 2 * h // 3 + 1, h]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            _, invs = make()
+            invs.set_native_row_margin(0)
+            invs.render_rows(dev + lo * w * 4, lo, hi)
+            invs.sync()
+            assert invs.direct_native_launches() == 1
+        striped = np.empty((h, w, 4), np.uint8)
+        assert lib().mmhip_copy_to_host(striped.ctypes.data_as(C.c_void_p), C.c_void_p(dev), w * h * 4) == 0
+    finally:
+        lib().mmhip_device_free(C.c_void_p(dev))
+    assert np.array_equal(striped, got)
+
     _, inv4 = make()                                       # a region inside the frame: direct write with offsets
     rx, ry, rw, rh = 16, 5, w - 40, h - 9
     reg = device_render(inv4, [(ry, ry + rh)], region=(rx, ry, rw, rh))
