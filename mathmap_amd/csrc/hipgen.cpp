@@ -409,6 +409,298 @@ struct Generator {
         out << ind << "}\n";
     }
 
+
+    // ---- pair mode: two pixels of a work-item evaluated in lockstep as 2-vectors ------------------
+    // For a pixel body that is nothing but int/float arithmetic, comparisons and structured control
+    // flow (Mandelbrot and its relatives), the two pixels a work-item renders per loop step are
+    // evaluated together: every SSA value is a 2-vector (x component: the first pixel), `if`s are
+    // if-converted (both sides evaluated -- the slice is pure -- and the exit phis select), a `while`
+    // runs while either pixel is active with the loop phis frozen per pixel by a select.  Each component
+    // sees exactly the scalar kernel's operations in the scalar kernel's order; what changes is that
+    // the float operations issue as v_pk_add_f32 / v_pk_mul_f32, two per instruction.
+    bool pair_mode = false;
+    std::set<const Value *> pair_defs;     // values defined in the pixel slice (vectors in pair mode)
+    int pair_ids = 0;
+
+    static bool pair_scalar_ty(Ty t) { return t == Ty::Int || t == Ty::Float; }
+    bool pair_prim_ok(const Primary &p) const {
+        if (p.kind == Primary::IntConst || p.kind == Primary::FloatConst) return true;
+        return p.kind == Primary::Val && pair_scalar_ty(p.value->var->type);
+    }
+    bool pair_rhs_ok(const Rhs &r) const {
+        if (r.kind == Rhs::Prim) return pair_prim_ok(r.prim);
+        if (r.kind == Rhs::Internal) return r.internal == "x" || r.internal == "y";
+        if (r.kind != Rhs::Op) return false;
+        static const char *ok[] = {"ADD", "SUB", "MUL", "NEG", "DIV", "LESS", "LEQ", "EQ", "NOT", "sqrt"};
+        bool found = false;
+        for (const char *o : ok) found = found || !strcmp(r.op->cname, o);
+        if (!found) return false;
+        for (const Primary &a : r.args) if (!pair_prim_ok(a)) return false;
+        if (!strcmp(r.op->cname, "sqrt") && r.args[0].type() != Ty::Float) return false;
+        if (!strcmp(r.op->cname, "NOT") && r.args[0].type() != Ty::Int) return false;
+        return true;
+    }
+    bool pair_block_ok(const Block &b) const {
+        for (const Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            switch (s->kind) {
+                case Stmt::Assign:
+                    if (!s->lhs || !pair_scalar_ty(s->lhs->var->type) || !pair_rhs_ok(s->rhs)) {
+                        if (getenv("MMHIP_PAIR_DEBUG"))
+                            fprintf(stderr, "pair mode: statement not covered (%s)\n",
+                                    s->rhs.kind == Rhs::Op ? s->rhs.op->cname : s->rhs.kind == Rhs::Internal ? s->rhs.internal.c_str() : "rhs kind");
+                        return false;
+                    }
+                    break;
+                case Stmt::If:
+                case Stmt::While:
+                    if (s->cond.kind != Rhs::Prim || !pair_prim_ok(s->cond.prim) || s->cond.prim.type() != Ty::Int) return false;
+                    for (const Stmt *ph : s->phis) {
+                        if (!ph->in_pixel) continue;
+                        if (!pair_scalar_ty(ph->lhs->var->type) || ph->rhs.kind != Rhs::Prim || ph->rhs2.kind != Rhs::Prim ||
+                            !pair_prim_ok(ph->rhs.prim) || !pair_prim_ok(ph->rhs2.prim))
+                            return false;
+                    }
+                    if (s->kind == Stmt::If ? !(pair_block_ok(s->then_) && pair_block_ok(s->else_)) : !pair_block_ok(s->body)) return false;
+                    break;
+                default: break;
+            }
+        }
+        return true;
+    }
+    bool pair_eligible() const {
+        if (!opt.fast_math_exact || !ks.natives.empty()) return false;
+        const char *force = getenv("MMHIP_PAIR");          // 0: never, 1: whenever the body is covered, unset: small bodies
+        if (force && !atoi(force)) return false;
+        int stmts = 0, fetches = 0;
+        pixel_stats(code.body, stmts, fetches);
+        // measured at 8192^2: Mandelbrot with its parameters baked in (24 statements) 0.372 -> 0.355 ms, the generic
+        // quaternion form (57 statements, four loop-carried components to keep per pixel) 0.75 -> 0.86 ms
+        if (fetches || stmts < 4 || stmts > (force ? 400 : 40)) return false;
+        const bool dbg = getenv("MMHIP_PAIR_DEBUG") != nullptr;
+        for (int i = 0; i < 4; ++i)
+            if (!code.result[i] || !pair_scalar_ty(code.result[i]->var->type)) {
+                if (dbg) fprintf(stderr, "pair mode: result %d is not an int / float value\n", i);
+                return false;
+            }
+        const bool ok = pair_block_ok(code.body);
+        if (dbg) fprintf(stderr, "pair mode: body %s (%d statements)\n", ok ? "covered" : "not covered", stmts);
+        return ok;
+    }
+    // Int values that only ever hold a truth value (results of comparisons, NOT, the literals 0 / 1 and
+    // phis / copies of such): kept as a pair of bools (mm_bb), which the compiler keeps in scalar lane masks
+    // where their logic is scalar arithmetic -- as ints they would cost two vector instructions per operation.
+    std::set<const Value *> pair_bools;
+    // a frame constant (scalar, defined in the hoisted slice) that holds a truth value
+    static bool pair_const_is_bool(const Value *v, int depth) {
+        if (!v || depth > 12 || v->var->type != Ty::Int) return false;
+        if (v->index < 0) return true;                      // uninitialised: reads as 0
+        const Stmt *d = v->def;
+        if (!d) return false;
+        auto prim_ok = [&](const Primary &p) {
+            if (p.kind == Primary::IntConst) return p.i == 0 || p.i == 1;
+            return p.kind == Primary::Val && pair_const_is_bool(p.value, depth + 1);
+        };
+        if (d->kind == Stmt::Phi) return d->rhs.kind == Rhs::Prim && d->rhs2.kind == Rhs::Prim && prim_ok(d->rhs.prim) && prim_ok(d->rhs2.prim);
+        if (d->kind != Stmt::Assign) return false;
+        if (d->rhs.kind == Rhs::Prim) return prim_ok(d->rhs.prim);
+        if (d->rhs.kind != Rhs::Op) return false;
+        const char *cn = d->rhs.op->cname;
+        return !strcmp(cn, "LESS") || !strcmp(cn, "LEQ") || !strcmp(cn, "EQ") || !strcmp(cn, "NOT");
+    }
+    bool pair_prim_bool(const Primary &p) const {
+        if (p.kind == Primary::IntConst) return p.i == 0 || p.i == 1;
+        if (p.kind != Primary::Val) return false;
+        if (p.value->index < 0) return p.value->var->type == Ty::Int;
+        if (pair_bools.count(p.value)) return true;
+        return !pair_defs.count(p.value) && pair_const_is_bool(p.value, 0);
+    }
+    void pair_collect_int_defs(const Block &b, std::vector<const Stmt *> &defs) const {
+        for (const Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            if (s->kind == Stmt::Assign && s->lhs->var->type == Ty::Int) defs.push_back(s);
+            if (s->kind == Stmt::If || s->kind == Stmt::While)
+                for (const Stmt *ph : s->phis) if (ph->in_pixel && ph->lhs->var->type == Ty::Int) defs.push_back(ph);
+            if (s->kind == Stmt::If) { pair_collect_int_defs(s->then_, defs); pair_collect_int_defs(s->else_, defs); }
+            if (s->kind == Stmt::While) pair_collect_int_defs(s->body, defs);
+        }
+    }
+    void pair_infer_bools() {
+        std::vector<const Stmt *> defs;
+        pair_collect_int_defs(code.body, defs);
+        for (Value *v : pix_defs) pair_defs.insert(v);
+        for (const Stmt *d : defs) pair_bools.insert(d->lhs);            // optimistic, then remove until stable
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (const Stmt *d : defs) {
+                if (!pair_bools.count(d->lhs)) continue;
+                bool ok;
+                if (d->kind == Stmt::Phi) ok = d->rhs.kind == Rhs::Prim && d->rhs2.kind == Rhs::Prim && pair_prim_bool(d->rhs.prim) && pair_prim_bool(d->rhs2.prim);
+                else if (d->rhs.kind == Rhs::Prim) ok = pair_prim_bool(d->rhs.prim);
+                else if (d->rhs.kind == Rhs::Op) {
+                    const char *cn = d->rhs.op->cname;
+                    ok = !strcmp(cn, "LESS") || !strcmp(cn, "LEQ") || !strcmp(cn, "EQ") || !strcmp(cn, "NOT");
+                } else ok = false;
+                if (!ok) { pair_bools.erase(d->lhs); changed = true; }
+            }
+        }
+    }
+    // values read outside the body of loop `w` (statements of other blocks, other loops' phis, the results):
+    // only those of w's phis, and its condition, have to keep their value once a pixel has left the loop
+    void pair_uses(const Block &b, const Stmt *skip, std::set<const Value *> &uses) const {
+        auto use = [&](const Primary &p) { if (p.kind == Primary::Val) uses.insert(p.value); };
+        auto use_rhs = [&](const Rhs &r) { if (r.kind == Rhs::Prim) use(r.prim); for (const Primary &a : r.args) use(a); };
+        for (const Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            if (s->kind == Stmt::Assign) use_rhs(s->rhs);
+            if (s->kind == Stmt::If) {
+                use_rhs(s->cond);
+                pair_uses(s->then_, skip, uses);
+                pair_uses(s->else_, skip, uses);
+                for (const Stmt *ph : s->phis) if (ph->in_pixel) { use_rhs(ph->rhs); use_rhs(ph->rhs2); }
+            }
+            if (s->kind == Stmt::While) {
+                for (const Stmt *ph : s->phis) if (ph->in_pixel) { use_rhs(ph->rhs); if (s != skip) use_rhs(ph->rhs2); }
+                if (s != skip) { use_rhs(s->cond); pair_uses(s->body, skip, uses); }
+            }
+        }
+    }
+
+    // operand as a 2-vector of the wanted type (mm_vf / mm_vi broadcast scalars and convert int -> float)
+    std::string pbool(const Primary &p) {        // operand as mm_bb
+        if (p.kind == Primary::IntConst) return p.i ? "mm_bb{true, true}" : "mm_bb{false, false}";
+        if (p.kind == Primary::Val && p.value->index < 0) return "mm_bb{false, false}";
+        if (pair_bools.count(p.value)) return vname(p.value);
+        return "mm_tob(" + pprim(p, Ty::Int) + ")";
+    }
+    std::string pprim(const Primary &p, Ty want) {
+        const char *w = want == Ty::Float ? "mm_vf(" : "mm_vi(";
+        if (p.kind == Primary::IntConst) return std::string(w) + std::to_string(p.i) + ")";
+        if (p.kind == Primary::FloatConst) return std::string(w) + float_literal(p.f) + "f)";
+        if (p.value->index < 0) return std::string(w) + "0)";
+        return std::string(w) + vname(p.value) + ")";
+    }
+    static Ty pair_arith_ty(const Rhs &r) {
+        for (const Primary &a : r.args) if (a.type() == Ty::Float) return Ty::Float;
+        return Ty::Int;
+    }
+    std::string prhs(const Rhs &r, const Value *lhs) {
+        const Ty lhs_ty = lhs->var->type;
+        const bool as_bool = pair_bools.count(lhs) > 0;
+        if (r.kind == Rhs::Prim) return as_bool ? pbool(r.prim) : pprim(r.prim, lhs_ty);
+        if (r.kind == Rhs::Internal) return r.internal == "x" ? "mm_vf(x)" : "mm_y2";
+        const char *cn = r.op->cname;
+        const Ty t = pair_arith_ty(r);
+        if (!strcmp(cn, "ADD")) return "(" + pprim(r.args[0], t) + " + " + pprim(r.args[1], t) + ")";
+        if (!strcmp(cn, "SUB")) return "(" + pprim(r.args[0], t) + " - " + pprim(r.args[1], t) + ")";
+        if (!strcmp(cn, "MUL")) return "(" + pprim(r.args[0], t) + " * " + pprim(r.args[1], t) + ")";
+        if (!strcmp(cn, "NEG")) return "(-" + pprim(r.args[0], t) + ")";
+        if (!strcmp(cn, "sqrt")) return "mm_sqrt2(" + pprim(r.args[0], Ty::Float) + ")";
+        if (!strcmp(cn, "DIV")) {
+            if (r.args[1].kind == Primary::FloatConst || r.args[1].kind == Primary::IntConst) {      // x / +-2^k = x * 2^-k, exactly
+                int ex = 0;
+                const float c = r.args[1].kind == Primary::FloatConst ? r.args[1].f : (float)r.args[1].i;
+                if (std::isfinite(c) && c != 0.0f && std::fabs(std::frexp(c, &ex)) == 0.5f && ex > -100 && ex < 100)
+                    return "(" + pprim(r.args[0], Ty::Float) + " * " + float_literal(1.0f / c) + "f)";
+            }
+            return "(" + pprim(r.args[0], Ty::Float) + " / " + pprim(r.args[1], Ty::Float) + ")";
+        }
+        // the truth-valued operators: a pair of bools; as an int (0 / 1) only if the value is used as one
+        std::string b;
+        if (!strcmp(cn, "NOT")) b = "mm_notb(" + pbool(r.args[0]) + ")";
+        else if (!strcmp(cn, "EQ") && pair_prim_bool(r.args[0]) && pair_prim_bool(r.args[1])) {
+            // b == 0 is !b, b == 1 is b, otherwise the equivalence of two truth values
+            const Primary &x = r.args[0], &y = r.args[1];
+            if (y.kind == Primary::IntConst) b = y.i ? pbool(x) : "mm_notb(" + pbool(x) + ")";
+            else if (x.kind == Primary::IntConst) b = x.i ? pbool(y) : "mm_notb(" + pbool(y) + ")";
+            else b = "mm_eqb(" + pbool(x) + ", " + pbool(y) + ")";
+        } else {
+            bool done = false;
+            if (!strcmp(cn, "LESS") && r.args[0].kind == Primary::Val && r.args[1].is_const()) {
+                // sqrt(a) < 2^k  ->  0 <= a < 4^k, like the scalar generator (rhs() above)
+                const Stmt *d = r.args[0].value->def;
+                double k = r.args[1].kind == Primary::IntConst ? (double)r.args[1].i : (double)r.args[1].f;
+                int ex = 0;
+                bool pow2 = k > 0 && std::frexp(k, &ex) == 0.5 && ex > -50 && ex < 50;
+                if (pow2 && d && d->kind == Stmt::Assign && d->rhs.kind == Rhs::Op && !strcmp(d->rhs.op->cname, "sqrt") &&
+                    d->lhs->var->type == Ty::Float && d->rhs.args[0].type() == Ty::Float && d->rhs.args[0].kind == Primary::Val &&
+                    value_visible(d->rhs.args[0].value, PIXEL)) {
+                    const std::string a = pprim(d->rhs.args[0], Ty::Float), k2 = "mm_vf(" + float_literal((float)(k * k)) + "f)";
+                    b = nonneg_or_nan(d->rhs.args[0].value, 0) ? "mm_lt(" + a + ", " + k2 + ")"
+                                                                 : "mm_andb(mm_lt(" + a + ", " + k2 + "), mm_le(mm_vf(0.0f), " + a + "))";
+                    done = true;
+                }
+            }
+            if (!done) {
+                const char *fn = !strcmp(cn, "LESS") ? "mm_lt(" : !strcmp(cn, "LEQ") ? "mm_le(" : "mm_eq(";
+                b = fn + pprim(r.args[0], t) + ", " + pprim(r.args[1], t) + ")";
+            }
+        }
+        return as_bool ? b : "mm_vi(" + b + ")";
+    }
+    static const char *pair_ctype(Ty t) { return t == Ty::Float ? "mm_f2" : "mm_i2"; }
+    void pair_decls(const std::vector<Value *> &defs, const std::string &ind) {
+        std::set<Value *> seen;
+        for (Value *v : defs) {
+            if (v->index < 0 || !seen.insert(v).second) continue;
+            out << ind << (pair_bools.count(v) ? "mm_bb" : pair_ctype(v->var->type)) << " " << vname(v) << ";\n";
+        }
+    }
+    std::string pval_as(const Primary &p, const Value *lhs) {      // operand in the representation of `lhs`
+        return pair_bools.count(lhs) ? pbool(p) : pprim(p, lhs->var->type);
+    }
+    // `mask`: the expression (mm_bb) under which the block runs
+    void pair_stmts(Block &b, const std::string &ind, const std::string &mask) {
+        for (Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            switch (s->kind) {
+                case Stmt::Assign:
+                    out << ind << vname(s->lhs) << " = " << prhs(s->rhs, s->lhs) << ";\n";
+                    break;
+                case Stmt::If: {
+                    const std::string c = "mm_c" + std::to_string(pair_ids++);
+                    out << ind << "const mm_bb " << c << " = " << pbool(s->cond.prim) << ";\n";
+                    pair_stmts(s->then_, ind, "mm_andb(" + mask + ", " + c + ")");
+                    pair_stmts(s->else_, ind, "mm_andb(" + mask + ", mm_notb(" + c + "))");
+                    for (Stmt *ph : s->phis)
+                        if (ph->in_pixel)
+                            out << ind << vname(ph->lhs) << " = mm_sel2(" << c << ", " << pval_as(ph->rhs.prim, ph->lhs) << ", "
+                                << pval_as(ph->rhs2.prim, ph->lhs) << ");\n";
+                    break;
+                }
+                case Stmt::While: {
+                    const std::string a = "mm_a" + std::to_string(pair_ids++);
+                    std::set<const Value *> outside;
+                    pair_uses(code.body, s, outside);
+                    for (int i = 0; i < 4; ++i) outside.insert(code.result[i]);
+                    if (s->cond.prim.kind == Primary::Val) outside.insert(s->cond.prim.value);
+                    for (Stmt *ph : s->phis)
+                        if (ph->in_pixel) out << ind << vname(ph->lhs) << " = " << pval_as(ph->rhs.prim, ph->lhs) << ";\n";
+                    out << ind << "mm_bb " << a << " = mm_andb(" << mask << ", " << pbool(s->cond.prim) << ");\n";
+                    out << ind << "while (" << a << ".x | " << a << ".y) {\n";
+                    pair_stmts(s->body, ind + "  ", a);
+                    // back edge: a parallel copy (temporaries first).  A phi that is read after the loop, and the
+                    // loop condition, keep their value once their pixel has left the loop; the others may run on.
+                    int k = 0;
+                    for (Stmt *ph : s->phis)
+                        if (ph->in_pixel) {
+                            const std::string ty = pair_bools.count(ph->lhs) ? "mm_bb" : pair_ctype(ph->lhs->var->type);
+                            const std::string nv = pval_as(ph->rhs2.prim, ph->lhs);
+                            out << ind << "  const " << ty << " " << a << "_n" << k++ << " = "
+                                << (outside.count(ph->lhs) ? "mm_sel2(" + a + ", " + nv + ", " + vname(ph->lhs) + ")" : nv) << ";\n";
+                        }
+                    k = 0;
+                    for (Stmt *ph : s->phis)
+                        if (ph->in_pixel) out << ind << "  " << vname(ph->lhs) << " = " << a << "_n" << k++ << ";\n";
+                    out << ind << "  " << a << " = mm_andb(" << a << ", " << pbool(s->cond.prim) << ");\n";
+                    out << ind << "}\n";
+                    break;
+                }
+                default: break;
+            }
+        }
+    }
+
     // sin(v) and cos(v) of the same float value in one block (toXY of an `ra` filter): evaluated
     // together by mmf_sincos_f32 -- one argument reduction -- at the first of the two statements.
     static bool is_fast_sincos(const Stmt *s, bool *is_sin) {
@@ -580,6 +872,8 @@ struct Generator {
         out << "#define MM_EDGE_X " << opt.edge_x << "\n#define MM_EDGE_Y " << opt.edge_y << "\n";
         out << "#define MM_TILE_W " << ks.tile_w << "\n#define MM_TILE_H " << ks.tile_h << "\n";
         ks.unroll = opt.unroll > 0 ? opt.unroll : auto_unroll();
+        pair_mode = opt.unroll <= 0 && !getenv("MMHIP_UNROLL") && pair_eligible();
+        if (pair_mode) { ks.unroll = 2; pair_infer_bools(); }
         out << "#define MM_UNROLL " << ks.unroll << "\n";
         // float-argument sin/cos (mm_fastmath.h), the same text the host verifier compiles; it
         // precedes the device prelude, whose complex functions use mmf_sincos_d
@@ -699,8 +993,28 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         // branch-free fetch their image loads are independent and overlap (one load per wave in
         // flight cannot cover HBM latency); rows past the end are computed on the last row and
         // simply not stored.  A.ppt is a multiple of MM_UNROLL (runtime.cpp).
+        if (ks.single_pixel) pair_mode = false;
         auto emit_loop = [&](const char *ind, bool hot) {
             std::string I = ind;
+            if (pair_mode) {
+                // two pixels (rows mm_p and mm_p + 1 of this work-item's column) in lockstep, see pair_stmts
+                out << "#pragma unroll 1\n" << I << "for (; mm_p < A.ppt; mm_p += 2) {\n"
+                    << I << "  // vertically adjacent pixels: they mostly take the same path (a wave covers 16 x 8 pixels per step)\n"
+                    << I << "  const int rl_a = row0 + (int)(threadIdx.x / MM_TILE_W) + mm_p * MM_TILE_H, rl_b = rl_a + 1;\n"
+                    << I << "  const int row_a = rl_a < A.num_rows ? rl_a : A.num_rows - 1, row_b = rl_b < A.num_rows ? rl_b : A.num_rows - 1;\n"
+                    << I << "  const mm_f2 mm_y2 = {A.ytab[row_a], A.ytab[row_b]};    // CALC_VIRTUAL_Y per row, by the prologue\n";
+                pair_decls(pix_defs, I + "  ");
+                pair_stmts(code.body, I + "  ", "mm_bb{true, true}");
+                out << I << "  mm_tup<4> mm_ra, mm_rb;\n";
+                for (int i = 0; i < 4; ++i) {
+                    const std::string v = pprim(Primary::V(code.result[i]), Ty::Float);
+                    out << I << "  mm_ra.v[" << i << "] = " << v << ".x; mm_rb.v[" << i << "] = " << v << ".y;\n";
+                }
+                out << I << "  // a row past the end was evaluated as the last row: storing it there again writes the same bytes\n"
+                    << I << "  mm_store_pixel(A, row_a, col, mm_ra);\n"
+                    << I << "  mm_store_pixel(A, row_b, col, mm_rb);\n" << I << "}\n";
+                return;
+            }
             out << "#pragma unroll 1\n" << I << "for (; mm_p < A.ppt; mm_p += MM_UNROLL) {\n"
                 << I << "  mm_tup<4> mm_rt[MM_UNROLL];\n"
                 << I << "  float mm_y[MM_UNROLL];\n"

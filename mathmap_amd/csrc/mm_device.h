@@ -204,6 +204,36 @@ MM_DEV float mm_sqrt_f32(float a) { return sqrtf(a); }   // correctly rounded (v
 // both sides (-0 gives true on both).  Saves the sqrt in escape-time tests `abs(z) < 2`.
 #define MM_SQRT_LESS_POW2(a, k2) (((a) < (k2)) && ((a) >= 0.0f))
 
+// ---- two pixels in lockstep (hipgen.cpp pair mode) ---------------------------------------------
+// Values of the pixel slice as 2-vectors; mm_vf / mm_vi make an operand a vector of the wanted type
+// (broadcasting frame constants and literals, converting int to float exactly like the C cast).
+typedef float mm_f2 __attribute__((ext_vector_type(2)));
+typedef int mm_i2 __attribute__((ext_vector_type(2)));
+MM_DEV mm_f2 mm_vf(float a) { return mm_f2{a, a}; }
+MM_DEV mm_f2 mm_vf(int a) { const float f = (float)a; return mm_f2{f, f}; }
+MM_DEV mm_f2 mm_vf(mm_f2 a) { return a; }
+MM_DEV mm_f2 mm_vf(mm_i2 a) { return mm_f2{(float)a.x, (float)a.y}; }
+MM_DEV mm_i2 mm_vi(int a) { return mm_i2{a, a}; }
+MM_DEV mm_i2 mm_vi(mm_i2 a) { return a; }
+// truth values (comparison results and their logic) as a pair of bools: scalar lane masks, scalar logic
+struct mm_bb { bool x, y; };
+MM_DEV mm_i2 mm_vi(mm_bb b) { return mm_i2{b.x ? 1 : 0, b.y ? 1 : 0}; }
+MM_DEV mm_f2 mm_vf(mm_bb b) { return mm_f2{b.x ? 1.0f : 0.0f, b.y ? 1.0f : 0.0f}; }
+MM_DEV mm_bb mm_tob(mm_i2 a) { return mm_bb{a.x != 0, a.y != 0}; }
+MM_DEV mm_bb mm_notb(mm_bb a) { return mm_bb{!a.x, !a.y}; }
+MM_DEV mm_bb mm_andb(mm_bb a, mm_bb b) { return mm_bb{a.x && b.x, a.y && b.y}; }
+MM_DEV mm_bb mm_eqb(mm_bb a, mm_bb b) { return mm_bb{a.x == b.x, a.y == b.y}; }
+MM_DEV mm_bb mm_lt(mm_f2 a, mm_f2 b) { return mm_bb{a.x < b.x, a.y < b.y}; }
+MM_DEV mm_bb mm_le(mm_f2 a, mm_f2 b) { return mm_bb{a.x <= b.x, a.y <= b.y}; }
+MM_DEV mm_bb mm_eq(mm_f2 a, mm_f2 b) { return mm_bb{a.x == b.x, a.y == b.y}; }
+MM_DEV mm_bb mm_lt(mm_i2 a, mm_i2 b) { return mm_bb{a.x < b.x, a.y < b.y}; }
+MM_DEV mm_bb mm_le(mm_i2 a, mm_i2 b) { return mm_bb{a.x <= b.x, a.y <= b.y}; }
+MM_DEV mm_bb mm_eq(mm_i2 a, mm_i2 b) { return mm_bb{a.x == b.x, a.y == b.y}; }
+MM_DEV mm_f2 mm_sel2(mm_bb c, mm_f2 a, mm_f2 b) { return mm_f2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
+MM_DEV mm_i2 mm_sel2(mm_bb c, mm_i2 a, mm_i2 b) { return mm_i2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
+MM_DEV mm_bb mm_sel2(mm_bb c, mm_bb a, mm_bb b) { return mm_bb{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
+MM_DEV mm_f2 mm_sqrt2(mm_f2 a) { return mm_f2{mm_sqrt_f32(a.x), mm_sqrt_f32(a.y)}; }
+
 // ---- complex (float _Complex) -----------------------------------------------------------
 // In the generated C, complex values only flow COMPLEX() -> c*f() -> crealf/cimagf
 // (builtins.lisp:679-941).  The functions below compute in double and round once;
@@ -586,7 +616,6 @@ MM_DEV mm_tup<4> mm_orig_val_d(const mm_args &A, float x, float y, mm_image img,
 // (checked once per work-item before the pixel loop), so nothing here branches and the loads
 // of consecutive unrolled pixels can overlap.  x * 1.0f is x, so the resize factors are
 // applied by multiplication with a selected factor instead of under `if (img.resized)`.
-typedef float mm_f2 __attribute__((ext_vector_type(2)));
 
 // k / 255 for an integer-valued float k in [0, 255], two channels at a time: bit-identical to
 // MM_BYTE_TO_UNIT's (float)((double)k * (1.0 / 255.0)) -- both are the correctly rounded

@@ -152,3 +152,50 @@ def make_filter(seed, with_image=True):
         params.insert(0, "image in")
     src = "filter fz%d (%s)\n  %s\n  %s\nend\n" % (seed, ", ".join(params), "\n  ".join(g.lines), result)
     return src, g.uses_image
+
+
+def make_filter_arith(seed):
+    """Arithmetic-only filters (+ - * /, comparisons, if, bounded and data-dependent while loops, int
+    counters): the class the generator evaluates two pixels at a time in packed f32 (hipgen.cpp pair mode)."""
+    r = random.Random(seed ^ 0xa217)
+    lines = []
+    names = ["x", "y"]
+
+    def atom():
+        c = r.random()
+        if c < 0.55:
+            return r.choice(names)
+        return r.choice(["0.5", "2", "3", "0.25", "1.5", "0.1", "%.3f" % r.uniform(0.05, 3), "k", "m"])
+
+    def expr(d):
+        if d <= 0 or r.random() < 0.25:
+            return atom()
+        op = r.choice(["+", "-", "*", "*", "+", "/"])
+        a, b = expr(d - 1), expr(d - 1)
+        if op == "/":
+            b = "(%s * %s + 0.5)" % (b, b)
+        return "(%s %s %s)" % (a, op, b)
+
+    def cond(d):
+        c = "%s %s %s" % (expr(d), r.choice(["<", ">", "<=", ">=", "=="]), expr(d))
+        if r.random() < 0.4:
+            c = "(%s) %s (%s %s %s)" % (c, r.choice(["&&", "||"]), expr(d), r.choice(["<", ">"]), expr(d))
+        return c
+
+    for i in range(r.randint(2, 5)):
+        v = "v%d" % i
+        c = r.random()
+        if c < 0.4:
+            lines.append("%s = %s;" % (v, expr(3)))
+        elif c < 0.65:
+            lines.append("%s = if %s then %s else %s end;" % (v, cond(2), expr(2), expr(2)))
+        else:
+            # escape-time style loop: data-dependent exit, bounded by a counter
+            n = "n%d" % i
+            lines.append("%s = %s; %s = 0; while (%s * %s < %s) && (%s < %s) do %s = %s * %s * 0.5 + %s; %s = %s + 1 end;" % (
+                v, expr(1), n, v, v, r.choice(["4", "9", "2.5"]), n, r.choice(["k + 2", "7", "12"]), v, v, r.choice([v, expr(1)]),
+                expr(1), n, n))
+            lines.append("%s = %s + %s * 0.1;" % (v, v, n))
+        names.append(v)
+    result = "rgba:[%s, %s, %s, 1]" % (expr(2), expr(2), names[-1])
+    return "filter fa%d (int k: 0-8 (3), float m: 0-2 (0.7))\n  %s\n  %s\nend\n" % (seed, "\n  ".join(lines), result)

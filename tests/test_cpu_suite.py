@@ -494,3 +494,21 @@ def test_elliptic_integrals_against_scipy():
             wd = quad(lambda t: np.sin(t) ** 2 / np.sqrt(1 - kk * kk * np.sin(t) ** 2), 0, p)[0]
             assert abs(gp[i, j] - wp) <= 5e-7 * abs(wp) + 1e-9 and abs(gd[i, j] - wd) <= 5e-7 * abs(wd) + 1e-9, (i, j)
     assert np.isnan(run("ell_int_Kcomp(1.5 + x * 0)")).all()           # k^2 >= 1: domain error
+
+
+def test_pair_mode_engages_for_arithmetic_filters(monkeypatch):
+    """hipgen.cpp pair mode (two pixels per work-item step as 2-vectors, packed f32): chosen for the
+    headline Mandelbrot filter with its parameters baked in (small bodies by default; MMHIP_PAIR=1 takes
+    every covered body, =0 none) and for the arithmetic-only fuzz filters; not for filters that fetch
+    pixels or call libm."""
+    from tests.fuzz_filters import make_filter_arith
+    monkeypatch.delenv("MMHIP_PAIR", raising=False)
+    marker = "mm_p += 2)"
+    flt = mm.Filter(W.MANDELBROT, specialize=True)
+    assert marker in flt.specialized({}).kernel_source and marker not in flt.kernel_source
+    monkeypatch.setenv("MMHIP_PAIR", "1")
+    assert marker in mm.Filter(W.MANDELBROT).kernel_source
+    assert sum(marker in mm.Filter(make_filter_arith(s)).kernel_source for s in range(40)) >= 35
+    assert marker not in mm.Filter(W.POND).kernel_source and marker not in mm.Filter(W.IDENT).kernel_source
+    monkeypatch.setenv("MMHIP_PAIR", "0")
+    assert marker not in mm.Filter(W.MANDELBROT).kernel_source

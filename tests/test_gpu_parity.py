@@ -895,6 +895,29 @@ def test_random_filters_with_closures_complex_ops_and_options(seed):
     assert mx <= 1 or n1 < 0.01 * want.size, "seed %d: max %d, %d differ, %d by more than 1\n%s" % (seed, mx, nd, n1, src)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_pair_mode_matches_scalar_kernel_and_oracle(seed, monkeypatch):
+    """Arithmetic-only filters are evaluated two pixels at a time in packed f32 (hipgen.cpp pair mode):
+    bytes identical to the one-pixel-at-a-time kernel (MMHIP_PAIR=0) and to the oracle, generic and with the
+    user values baked in, on a ragged frame (odd height: the last pair has one row)."""
+    from tests.fuzz_filters import make_filter_arith
+    src = make_filter_arith(seed)
+    w, h = 83, 61
+    uv = {"k": seed % 7, "m": 0.3 + (seed % 5) * 0.4}
+    outs = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("MMHIP_PAIR", pair)
+        for spec in (False, True):
+            flt = mm.Filter(src, specialize=spec)
+            inv = flt.invoke(w, h)
+            for k, v in uv.items():
+                inv.set(k, v)
+            outs[pair, spec] = inv.render(t=0.3)
+    want = CpuFilter(mm.Filter(src).ir_json).render(w, h, uservals=uv, t=0.3)
+    for key, got in outs.items():
+        assert np.array_equal(got, want), (key, stats(got, want), src)
+
+
 def _example_manifest():
     import json
     import os
