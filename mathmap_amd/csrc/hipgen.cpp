@@ -13,9 +13,11 @@
 //                      MM_UNROLL pixels evaluated back to back (stores deferred), with a branch-free
 //                      "hot" copy of the loop when every fetch reads a bound drawable
 //       single shape : one pixel per work-item, lazy scalar loads (large bodies: no SGPR spills)
+//       pair mode    : loop shape for small arithmetic-only bodies -- two vertically adjacent pixels as
+//                      2-vectors in lockstep (packed f32), see pair_stmts
 //
 // Environment hooks for experiments (never needed for correct operation): MMHIP_UNROLL,
-// MMHIP_SINGLE_PIXEL, MMHIP_WAVES_PER_EU here; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE,
+// MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU here; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE,
 // MMHIP_CACHE_DIR in runtime.cpp.
 //
 // Statement printing follows the reference's backends/cc.c:192-397 (one C variable
