@@ -14,7 +14,7 @@
 //                      "hot" copy of the loop when every fetch reads a bound drawable
 //       single shape : one pixel per work-item, lazy scalar loads (large bodies: no SGPR spills)
 //       pair mode    : loop shape for small arithmetic-only bodies -- two vertically adjacent pixels as
-//                      2-vectors in lockstep (packed f32), see pair_stmts
+//                      pairs of values in lockstep (two interleaved instruction streams), see pair_stmts
 //
 // Environment hooks for experiments (never needed for correct operation): MMHIP_UNROLL,
 // MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU here; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE,
@@ -418,8 +418,14 @@ struct Generator {
     // evaluated together: every SSA value is a 2-vector (x component: the first pixel), `if`s are
     // if-converted (both sides evaluated -- the slice is pure -- and the exit phis select), a `while`
     // runs while either pixel is active with the loop phis frozen per pixel by a select.  Each component
-    // sees exactly the scalar kernel's operations in the scalar kernel's order; what changes is that
-    // the float operations issue as v_pk_add_f32 / v_pk_mul_f32, two per instruction.
+    // sees exactly the scalar kernel's operations in the scalar kernel's order.  What it buys: a gfx950
+    // SIMD hands a wave an issue slot every ~4 cycles, in which the wave can issue two independent vector
+    // instructions (2 cycles each) -- a single pixel's dependent chain uses half of that, whatever the
+    // occupancy (tools/pk_rate.hip: dependent v_mul/v_add 4.25 cycles per instruction at 8 waves per SIMD,
+    // two independent chains 2.4).  The pair's components are kept as separate scalars, so the
+    // instruction stream alternates between the two pixels; as v_pk_*_f32 (MM_PAIR_SCALAR=0) the same
+    // work issues in one 4-cycle instruction and gains much less (Mandelbrot 8192^2: 0.372 ms one pixel
+    // at a time, 0.360 packed, 0.313 interleaved).
     bool pair_mode = false;
     std::set<const Value *> pair_defs;     // values defined in the pixel slice (vectors in pair mode)
     int pair_ids = 0;
@@ -640,7 +646,7 @@ struct Generator {
         }
         return as_bool ? b : "mm_vi(" + b + ")";
     }
-    static const char *pair_ctype(Ty t) { return t == Ty::Float ? "mm_f2" : "mm_i2"; }
+    static const char *pair_ctype(Ty t) { return t == Ty::Float ? "mm_pf" : "mm_pi"; }
     void pair_decls(const std::vector<Value *> &defs, const std::string &ind) {
         std::set<Value *> seen;
         for (Value *v : defs) {
@@ -1004,7 +1010,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                     << I << "  // vertically adjacent pixels: they mostly take the same path (a wave covers 16 x 8 pixels per step)\n"
                     << I << "  const int rl_a = row0 + (int)(threadIdx.x / MM_TILE_W) + mm_p * MM_TILE_H, rl_b = rl_a + 1;\n"
                     << I << "  const int row_a = rl_a < A.num_rows ? rl_a : A.num_rows - 1, row_b = rl_b < A.num_rows ? rl_b : A.num_rows - 1;\n"
-                    << I << "  const mm_f2 mm_y2 = {A.ytab[row_a], A.ytab[row_b]};    // CALC_VIRTUAL_Y per row, by the prologue\n";
+                    << I << "  const mm_pf mm_y2 = {A.ytab[row_a], A.ytab[row_b]};    // CALC_VIRTUAL_Y per row, by the prologue\n";
                 pair_decls(pix_defs, I + "  ");
                 pair_stmts(code.body, I + "  ", "mm_bb{true, true}");
                 out << I << "  mm_tup<4> mm_ra, mm_rb;\n";

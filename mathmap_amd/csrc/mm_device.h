@@ -209,30 +209,51 @@ MM_DEV float mm_sqrt_f32(float a) { return sqrtf(a); }   // correctly rounded (v
 // (broadcasting frame constants and literals, converting int to float exactly like the C cast).
 typedef float mm_f2 __attribute__((ext_vector_type(2)));
 typedef int mm_i2 __attribute__((ext_vector_type(2)));
-MM_DEV mm_f2 mm_vf(float a) { return mm_f2{a, a}; }
-MM_DEV mm_f2 mm_vf(int a) { const float f = (float)a; return mm_f2{f, f}; }
-MM_DEV mm_f2 mm_vf(mm_f2 a) { return a; }
-MM_DEV mm_f2 mm_vf(mm_i2 a) { return mm_f2{(float)a.x, (float)a.y}; }
-MM_DEV mm_i2 mm_vi(int a) { return mm_i2{a, a}; }
-MM_DEV mm_i2 mm_vi(mm_i2 a) { return a; }
+#ifndef MM_PAIR_SCALAR
+#define MM_PAIR_SCALAR 1
+#endif
+#if MM_PAIR_SCALAR
+// the two components as separate scalars: adjacent independent v_*_f32 instead of one v_pk_*_f32
+struct mm_pf { float x, y; };
+struct mm_pi { int x, y; };
+MM_DEV mm_pf operator+(mm_pf a, mm_pf b) { return mm_pf{a.x + b.x, a.y + b.y}; }
+MM_DEV mm_pf operator-(mm_pf a, mm_pf b) { return mm_pf{a.x - b.x, a.y - b.y}; }
+MM_DEV mm_pf operator*(mm_pf a, mm_pf b) { return mm_pf{a.x * b.x, a.y * b.y}; }
+MM_DEV mm_pf operator/(mm_pf a, mm_pf b) { return mm_pf{a.x / b.x, a.y / b.y}; }
+MM_DEV mm_pf operator*(mm_pf a, float b) { return mm_pf{a.x * b, a.y * b}; }
+MM_DEV mm_pf operator-(mm_pf a) { return mm_pf{-a.x, -a.y}; }
+MM_DEV mm_pi operator+(mm_pi a, mm_pi b) { return mm_pi{a.x + b.x, a.y + b.y}; }
+MM_DEV mm_pi operator-(mm_pi a, mm_pi b) { return mm_pi{a.x - b.x, a.y - b.y}; }
+MM_DEV mm_pi operator*(mm_pi a, mm_pi b) { return mm_pi{a.x * b.x, a.y * b.y}; }
+MM_DEV mm_pi operator-(mm_pi a) { return mm_pi{-a.x, -a.y}; }
+#else
+typedef mm_f2 mm_pf;
+typedef mm_i2 mm_pi;
+#endif
+MM_DEV mm_pf mm_vf(float a) { return mm_pf{a, a}; }
+MM_DEV mm_pf mm_vf(int a) { const float f = (float)a; return mm_pf{f, f}; }
+MM_DEV mm_pf mm_vf(mm_pf a) { return a; }
+MM_DEV mm_pf mm_vf(mm_pi a) { return mm_pf{(float)a.x, (float)a.y}; }
+MM_DEV mm_pi mm_vi(int a) { return mm_pi{a, a}; }
+MM_DEV mm_pi mm_vi(mm_pi a) { return a; }
 // truth values (comparison results and their logic) as a pair of bools: scalar lane masks, scalar logic
 struct mm_bb { bool x, y; };
-MM_DEV mm_i2 mm_vi(mm_bb b) { return mm_i2{b.x ? 1 : 0, b.y ? 1 : 0}; }
-MM_DEV mm_f2 mm_vf(mm_bb b) { return mm_f2{b.x ? 1.0f : 0.0f, b.y ? 1.0f : 0.0f}; }
-MM_DEV mm_bb mm_tob(mm_i2 a) { return mm_bb{a.x != 0, a.y != 0}; }
+MM_DEV mm_pi mm_vi(mm_bb b) { return mm_pi{b.x ? 1 : 0, b.y ? 1 : 0}; }
+MM_DEV mm_pf mm_vf(mm_bb b) { return mm_pf{b.x ? 1.0f : 0.0f, b.y ? 1.0f : 0.0f}; }
+MM_DEV mm_bb mm_tob(mm_pi a) { return mm_bb{a.x != 0, a.y != 0}; }
 MM_DEV mm_bb mm_notb(mm_bb a) { return mm_bb{!a.x, !a.y}; }
 MM_DEV mm_bb mm_andb(mm_bb a, mm_bb b) { return mm_bb{a.x && b.x, a.y && b.y}; }
 MM_DEV mm_bb mm_eqb(mm_bb a, mm_bb b) { return mm_bb{a.x == b.x, a.y == b.y}; }
-MM_DEV mm_bb mm_lt(mm_f2 a, mm_f2 b) { return mm_bb{a.x < b.x, a.y < b.y}; }
-MM_DEV mm_bb mm_le(mm_f2 a, mm_f2 b) { return mm_bb{a.x <= b.x, a.y <= b.y}; }
-MM_DEV mm_bb mm_eq(mm_f2 a, mm_f2 b) { return mm_bb{a.x == b.x, a.y == b.y}; }
-MM_DEV mm_bb mm_lt(mm_i2 a, mm_i2 b) { return mm_bb{a.x < b.x, a.y < b.y}; }
-MM_DEV mm_bb mm_le(mm_i2 a, mm_i2 b) { return mm_bb{a.x <= b.x, a.y <= b.y}; }
-MM_DEV mm_bb mm_eq(mm_i2 a, mm_i2 b) { return mm_bb{a.x == b.x, a.y == b.y}; }
-MM_DEV mm_f2 mm_sel2(mm_bb c, mm_f2 a, mm_f2 b) { return mm_f2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
-MM_DEV mm_i2 mm_sel2(mm_bb c, mm_i2 a, mm_i2 b) { return mm_i2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
+MM_DEV mm_bb mm_lt(mm_pf a, mm_pf b) { return mm_bb{a.x < b.x, a.y < b.y}; }
+MM_DEV mm_bb mm_le(mm_pf a, mm_pf b) { return mm_bb{a.x <= b.x, a.y <= b.y}; }
+MM_DEV mm_bb mm_eq(mm_pf a, mm_pf b) { return mm_bb{a.x == b.x, a.y == b.y}; }
+MM_DEV mm_bb mm_lt(mm_pi a, mm_pi b) { return mm_bb{a.x < b.x, a.y < b.y}; }
+MM_DEV mm_bb mm_le(mm_pi a, mm_pi b) { return mm_bb{a.x <= b.x, a.y <= b.y}; }
+MM_DEV mm_bb mm_eq(mm_pi a, mm_pi b) { return mm_bb{a.x == b.x, a.y == b.y}; }
+MM_DEV mm_pf mm_sel2(mm_bb c, mm_pf a, mm_pf b) { return mm_pf{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
+MM_DEV mm_pi mm_sel2(mm_bb c, mm_pi a, mm_pi b) { return mm_pi{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
 MM_DEV mm_bb mm_sel2(mm_bb c, mm_bb a, mm_bb b) { return mm_bb{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
-MM_DEV mm_f2 mm_sqrt2(mm_f2 a) { return mm_f2{mm_sqrt_f32(a.x), mm_sqrt_f32(a.y)}; }
+MM_DEV mm_pf mm_sqrt2(mm_pf a) { return mm_pf{mm_sqrt_f32(a.x), mm_sqrt_f32(a.y)}; }
 
 // ---- complex (float _Complex) -----------------------------------------------------------
 // In the generated C, complex values only flow COMPLEX() -> c*f() -> crealf/cimagf

@@ -156,7 +156,7 @@ def make_filter(seed, with_image=True):
 
 def make_filter_arith(seed):
     """Arithmetic-only filters (+ - * /, comparisons, if, bounded and data-dependent while loops, int
-    counters): the class the generator evaluates two pixels at a time in packed f32 (hipgen.cpp pair mode)."""
+    counters): the class the generator evaluates two pixels at a time in lockstep (hipgen.cpp pair mode)."""
     r = random.Random(seed ^ 0xa217)
     lines = []
     names = ["x", "y"]

@@ -497,7 +497,7 @@ def test_elliptic_integrals_against_scipy():
 
 
 def test_pair_mode_engages_for_arithmetic_filters(monkeypatch):
-    """hipgen.cpp pair mode (two pixels per work-item step as 2-vectors, packed f32): chosen for the
+    """hipgen.cpp pair mode (two pixels per work-item step in lockstep): chosen for the
     headline Mandelbrot filter with its parameters baked in (small bodies by default; MMHIP_PAIR=1 takes
     every covered body, =0 none) and for the arithmetic-only fuzz filters; not for filters that fetch
     pixels or call libm."""

@@ -897,7 +897,7 @@ def test_random_filters_with_closures_complex_ops_and_options(seed):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_pair_mode_matches_scalar_kernel_and_oracle(seed, monkeypatch):
-    """Arithmetic-only filters are evaluated two pixels at a time in packed f32 (hipgen.cpp pair mode):
+    """Arithmetic-only filters are evaluated two pixels at a time in lockstep (hipgen.cpp pair mode):
     bytes identical to the one-pixel-at-a-time kernel (MMHIP_PAIR=0) and to the oracle, generic and with the
     user values baked in, on a ragged frame (odd height: the last pair has one row)."""
     from tests.fuzz_filters import make_filter_arith
