@@ -918,6 +918,39 @@ def test_pair_mode_matches_scalar_kernel_and_oracle(seed, monkeypatch):
         assert np.array_equal(got, want), (key, stats(got, want), src)
 
 
+PAIR_NESTED = """filter t (int k: 0-8 (3), float m: 0-2 (0.7))
+  v0 = if x * y < 0.1 then (w = x + 0.3; n = 0; while (w * w < 4) && (n < k + 3) do w = w * w * 0.5 + y; n = n + 1 end; w + n * 0.1) else (y * 0.5) end;
+  u = 0; q = x;
+  while u < 3 do
+    p = 0; rr = q;
+    while (rr * rr < 2.5) && (p < 4) do rr = rr * 1.3 + 0.2; p = p + 1 end;
+    q = q * 0.7 + rr * 0.1 + p * m * 0.01;
+    u = u + 1
+  end;
+  rgba:[v0, q, x * y, 1]
+end
+"""
+
+
+def test_pair_mode_nested_control_flow(monkeypatch):
+    """Pair mode with a data-dependent loop inside a conditional and a loop nest whose inner trip count differs
+    between the two pixels of a pair: same bytes as the one-pixel kernel and the oracle."""
+    w, h = 131, 77
+    uv = {"k": 4, "m": 1.1}
+    outs = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("MMHIP_PAIR", pair)
+        flt = mm.Filter(PAIR_NESTED)
+        assert ("mm_p += 2)" in flt.kernel_source) == (pair == "1")
+        inv = flt.invoke(w, h)
+        for k, v in uv.items():
+            inv.set(k, v)
+        outs[pair] = inv.render()
+    want = CpuFilter(mm.Filter(PAIR_NESTED).ir_json).render(w, h, uservals=uv)
+    assert np.array_equal(outs["0"], want), stats(outs["0"], want)
+    assert np.array_equal(outs["1"], want), stats(outs["1"], want)
+
+
 def _example_manifest():
     import json
     import os
