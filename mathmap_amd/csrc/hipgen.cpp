@@ -599,6 +599,27 @@ struct Generator {
         if (r.kind == Rhs::Internal) return r.internal == "x" ? "mm_vf(x)" : "mm_y2";
         const char *cn = r.op->cname;
         const Ty t = pair_arith_ty(r);
+        // An int value next to a float literal: the scalar kernel's literal is a double (cc.c prints them so),
+        // C computes (double)i op literal and the assignment rounds once -- (float)i first would round twice
+        // for |i| >= 2^24.  Same arithmetic here, per component.
+        if (r.args.size() == 2 && ((r.args[0].type() == Ty::Int && r.args[1].kind == Primary::FloatConst) ||
+                                   (r.args[1].type() == Ty::Int && r.args[0].kind == Primary::FloatConst))) {
+            const char *op = !strcmp(cn, "ADD") ? "+" : !strcmp(cn, "SUB") ? "-" : !strcmp(cn, "MUL") ? "*" : !strcmp(cn, "LESS") ? "<"
+                             : !strcmp(cn, "LEQ") ? "<=" : !strcmp(cn, "EQ") ? "==" : nullptr;
+            if (op) {
+                auto comp = [&](const Primary &p, const char *c) {
+                    if (p.kind == Primary::FloatConst) return "(double)" + float_literal(p.f) + "f";
+                    return "(double)" + pprim(p, Ty::Int) + "." + c;
+                };
+                const std::string ex = comp(r.args[0], "x") + " " + op + " " + comp(r.args[1], "x");
+                const std::string ey = comp(r.args[0], "y") + " " + op + " " + comp(r.args[1], "y");
+                if (op[0] == '<' || op[0] == '=') {
+                    const std::string b = "mm_bb{" + ex + ", " + ey + "}";
+                    return as_bool ? b : "mm_vi(" + b + ")";
+                }
+                return "mm_pf{(float)(" + ex + "), (float)(" + ey + ")}";
+            }
+        }
         if (!strcmp(cn, "ADD")) return "(" + pprim(r.args[0], t) + " + " + pprim(r.args[1], t) + ")";
         if (!strcmp(cn, "SUB")) return "(" + pprim(r.args[0], t) + " - " + pprim(r.args[1], t) + ")";
         if (!strcmp(cn, "MUL")) return "(" + pprim(r.args[0], t) + " * " + pprim(r.args[1], t) + ")";

@@ -932,21 +932,32 @@ end
 """
 
 
-def test_pair_mode_nested_control_flow(monkeypatch):
+PAIR_BIG_INTS = """filter t (int k: 0-8 (3), float m: 0-2 (0.7))
+  n = 0; w = x;
+  while (w * w < 4) && (n < k + 9) do w = w * w + y; n = n + 1 end;
+  big = n * 3000000 + k;
+  rgba:[big * 0.0000001, (big + 0.25) * 0.00000003 * m, if big < 16777217.5 then 0.2 else 0.9 end, 1]
+end
+"""
+
+
+@pytest.mark.parametrize("src", [PAIR_NESTED, PAIR_BIG_INTS], ids=["nested", "big_ints"])
+def test_pair_mode_nested_control_flow(src, monkeypatch):
     """Pair mode with a data-dependent loop inside a conditional and a loop nest whose inner trip count differs
-    between the two pixels of a pair: same bytes as the one-pixel kernel and the oracle."""
+    between the two pixels of a pair; and with ints beyond 2^24 next to float literals (C computes those in
+    double and rounds once): same bytes as the one-pixel kernel and the oracle."""
     w, h = 131, 77
     uv = {"k": 4, "m": 1.1}
     outs = {}
     for pair in ("1", "0"):
         monkeypatch.setenv("MMHIP_PAIR", pair)
-        flt = mm.Filter(PAIR_NESTED)
+        flt = mm.Filter(src)
         assert ("mm_p += 2)" in flt.kernel_source) == (pair == "1")
         inv = flt.invoke(w, h)
         for k, v in uv.items():
             inv.set(k, v)
         outs[pair] = inv.render()
-    want = CpuFilter(mm.Filter(PAIR_NESTED).ir_json).render(w, h, uservals=uv)
+    want = CpuFilter(mm.Filter(src).ir_json).render(w, h, uservals=uv)
     assert np.array_equal(outs["0"], want), stats(outs["0"], want)
     assert np.array_equal(outs["1"], want), stats(outs["1"], want)
 
