@@ -40,6 +40,11 @@ void mathmap_hip_set_get_pixel(mmabi_get_pixel_func_t fn);
 /* Drops the HBM copy of an input drawable (call when its pixels changed). */
 void mathmap_hip_invalidate_drawable(mmabi_input_drawable_t *drawable);
 
+/* Drops the device-side state kept for a host invocation (stream, buffers, native-filter memo).
+ * Optional hook for free_invocation (mathmap_common.c:303-319): without it the backend keeps at
+ * most a handful of invocations per filter and recycles the rest. */
+void mathmap_hip_release_invocation(mmabi_invocation_t *invocation);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,7 +74,11 @@ void mmhip_filter_free(mmhip_filter *f);
 const char *mmhip_filter_name(const mmhip_filter *f);
 int mmhip_filter_num_uservals(const mmhip_filter *f);
 int mmhip_filter_userval_info(const mmhip_filter *f, int index, mmhip_userval_info *out);
-const char *mmhip_filter_ir_json(mmhip_filter *f);        /* IR dump, see oracle/ccgen.py */
+const char *mmhip_filter_ir_json(mmhip_filter *f);        /* IR dump after the optimisation passes */
+/* IR dump straight out of lowering (or the reference-ABI importer), before constant specialisation,
+   copy propagation / DCE, loop-carried CSE and frame-constant hoisting: the input of
+   mmhip_compile_ir_json and of the test oracle (oracle/ccgen.py) */
+const char *mmhip_filter_ir_json_raw(mmhip_filter *f);
 const char *mmhip_filter_kernel_source(mmhip_filter *f);  /* the HIP C++ handed to hiprtc */
 int mmhip_filter_num_native_calls(const mmhip_filter *f);
 /* hiprtc-compiles for gfx950 and (if a device is present) loads the module.

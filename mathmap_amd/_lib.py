@@ -38,6 +38,7 @@ SYMBOLS = {
     "mmhip_filter_num_uservals": (C.c_int, [C.c_void_p]),
     "mmhip_filter_userval_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(UservalInfo)]),
     "mmhip_filter_ir_json": (C.c_char_p, [C.c_void_p]),
+    "mmhip_filter_ir_json_raw": (C.c_char_p, [C.c_void_p]),
     "mmhip_filter_kernel_source": (C.c_char_p, [C.c_void_p]),
     "mmhip_filter_num_native_calls": (C.c_int, [C.c_void_p]),
     "mmhip_filter_jit": (C.c_long, [C.c_void_p, C.c_int]),
@@ -81,6 +82,7 @@ BACKEND_SYMBOLS = {
     "unload_hip_code": (None, [C.c_void_p]),
     "mathmap_hip_set_get_pixel": (None, [C.c_void_p]),
     "mathmap_hip_invalidate_drawable": (None, [C.c_void_p]),
+    "mathmap_hip_release_invocation": (None, [C.c_void_p]),
     "mmhip_selftest_abi_roundtrip": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "mmhip_selftest_error": (C.c_char_p, []),

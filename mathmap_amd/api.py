@@ -91,6 +91,12 @@ class Filter:
         return lib().mmhip_filter_ir_json(self._h).decode()
 
     @property
+    def ir_json_raw(self):
+        """The IR before any optimisation pass (what mmhip_compile_ir_json takes and the test
+        oracle prints): lowering output only."""
+        return lib().mmhip_filter_ir_json_raw(self._h).decode()
+
+    @property
     def needs_constants(self):
         """True for a filter that only compiles once its scalar user values are literals
         (recursion whose depth they control): it has no generic IR/kernel, every render
@@ -142,6 +148,7 @@ class Invocation:
     def __init__(self, flt, width, height):
         self.filter = flt
         self.width, self.height = width, height
+        self.render_width, self.render_height = width, height
         self._h = lib().mmhip_invoke(flt._h, width, height)
         if not self._h:
             raise MathMapError(_err())
@@ -215,6 +222,12 @@ class Invocation:
         reads, +- `margin` rows, plus their own halo.  -1 restores whole maps."""
         self._check(lib().mmhip_set_native_row_margin(self._h, margin))
 
+    def set_render_size(self, render_width, render_height):
+        """Renders the canvas at another pixel size (the GIMP preview, mathmap.c:2191-2223);
+        `render()` then returns an array of that size."""
+        self._check(lib().mmhip_set_render_size(self._h, render_width, render_height))
+        self.render_width, self.render_height = render_width, render_height
+
     def set_edge_colors(self, cx, cy):
         self._check(lib().mmhip_set_edge_colors(self._h, cx, cy))
 
@@ -238,7 +251,7 @@ class Invocation:
 
     def render(self, t=0.0, frame=0):
         """Renders the whole frame and returns it as a uint8 [H,W,4] array (RGBA)."""
-        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        out = np.empty((self.render_height, self.render_width, 4), dtype=np.uint8)
         self._check(lib().mmhip_render_host(self._h, frame, t, out.ctypes.data_as(C.c_void_p)))
         return out
 
@@ -246,7 +259,7 @@ class Invocation:
                     stream=0, region=None):
         """Asynchronously renders rows [first_row,last_row) into device memory at out_ptr
         (the reference's calc_lines band, mathmap_common.c:837-846)."""
-        rx, ry, rw, rh = region if region is not None else (0, 0, self.width, self.height)
+        rx, ry, rw, rh = region if region is not None else (0, 0, self.render_width, self.render_height)
         if row_stride is None:
             row_stride = rw * bpp
         self._check(lib().mmhip_render(self._h, frame, t, rx, ry, rw, rh, first_row, last_row, C.c_void_p(out_ptr),
@@ -254,8 +267,8 @@ class Invocation:
 
     def render_supersampled(self, out_ptr, t=0.0, frame=0, bpp=4, stream=0):
         """The CLI's -o (supersampling) for the whole frame, into device memory at out_ptr."""
-        self._check(lib().mmhip_render_supersampled(self._h, frame, t, 0, 0, self.width, self.height, C.c_void_p(out_ptr),
-                                                    self.width * bpp, bpp, C.c_void_p(stream)))
+        self._check(lib().mmhip_render_supersampled(self._h, frame, t, 0, 0, self.render_width, self.render_height,
+                                                    C.c_void_p(out_ptr), self.render_width * bpp, bpp, C.c_void_p(stream)))
 
     def sync(self):
         self._check(lib().mmhip_sync(self._h))

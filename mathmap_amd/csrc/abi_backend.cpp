@@ -341,7 +341,21 @@ void hip_calc_lines(mmabi_slice_t *slice, mmabi_image_t *closure, int first_row,
     Variant *v = get_variant(mi, inv);
     if (!v) return;
     mmhip_invocation *&hi = v->invs[inv];
+    // a host invocation allocated at a recycled address after the old one was freed: the canvas size
+    // tells them apart (everything else is re-sent below with every call)
+    if (hi && (hi->img_w != inv->img_width || hi->img_h != inv->img_height)) {
+        mmhip_invocation_free(hi);
+        hi = nullptr;
+    }
     if (!hi) {
+        // bound the cache: hosts that never call mathmap_hip_release_invocation (the reference has no
+        // hook in free_invocation) would otherwise leak a stream and buffers per invocation.  `hi`
+        // refers to the entry of `inv`, which stays (std::map references survive other erasures).
+        if (v->invs.size() > 8)
+            for (auto it = v->invs.begin(); it != v->invs.end();) {
+                if (it->first != inv) { if (it->second) mmhip_invocation_free(it->second); it = v->invs.erase(it); }
+                else ++it;
+            }
         hi = mmhip_invoke(v->flt, inv->img_width, inv->img_height);
         if (!hi) { host_error(std::string("HIP backend: ") + mmhip_last_error()); return; }
     }
@@ -414,7 +428,9 @@ void hip_calc_lines(mmabi_slice_t *slice, mmabi_image_t *closure, int first_row,
     if (rc != 0) { host_error(std::string("HIP backend: ") + mmhip_last_error()); return; }
     mmhip_sync(hi);
     if (floatmap) {
-        (void)hipMemcpy(q, mi->staging, need, hipMemcpyDeviceToHost);
+        // rows are frame_render_width float4s apart on both sides (new_template.c.in:297); only the
+        // region's columns were rendered
+        (void)hipMemcpy2D(q, dev_stride, mi->staging, dev_stride, (size_t)slice->region_width * 16, (size_t)rows, hipMemcpyDeviceToHost);
     } else {
         (void)hipMemcpy2D(q, (size_t)inv->row_stride, mi->staging, dev_stride, dev_stride, (size_t)rows, hipMemcpyDeviceToHost);
     }
@@ -524,18 +540,45 @@ void unload_hip_code(void *module_info) {
 
 void mathmap_hip_set_get_pixel(mmabi_get_pixel_func_t fn) { g_get_pixel = fn; }
 
+// Lock order: mi->mu before g_registry_mu (hip_calc_lines registers a drawable while it holds the
+// module's lock), so the owner is looked up and unregistered first and the registry lock released
+// before the module is locked.  The host must not unload the module concurrently (it never does:
+// both are main-thread operations).
 void mathmap_hip_invalidate_drawable(mmabi_input_drawable_t *drawable) {
-    std::lock_guard<std::mutex> g(g_registry_mu);
-    auto it = g_drawable_owner.find(drawable);
-    if (it == g_drawable_owner.end()) return;
-    ModuleInfo *mi = it->second;
-    std::lock_guard<std::mutex> g2(mi->mu);
+    ModuleInfo *mi = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_registry_mu);
+        auto it = g_drawable_owner.find(drawable);
+        if (it == g_drawable_owner.end()) return;
+        mi = it->second;
+        g_drawable_owner.erase(it);
+    }
+    std::lock_guard<std::mutex> g2(mi->mu);     // waits for a render in flight
     auto d = mi->drawables.find(drawable);
     if (d != mi->drawables.end()) {
+        for (auto &v : mi->variants)            // no invocation may keep the freed pointer bound
+            for (auto &i : v.second.invs)
+                if (i.second)
+                    for (auto &img : i.second->images)
+                        if (img.data == d->second.dev) { img.kind = IMG_NULL; img.data = nullptr; i.second->tables_dirty = true; ++i.second->input_generation; }
+        (void)hipDeviceSynchronize();
         if (d->second.dev) (void)hipFree(d->second.dev);
         mi->drawables.erase(d);
     }
-    g_drawable_owner.erase(it);
+}
+
+// Drops the device-side state (stream, buffers, native-filter memo) kept for a host invocation; call
+// it from free_invocation (mathmap_common.c:303-319).  Optional: the cache is bounded without it.
+void mathmap_hip_release_invocation(mmabi_invocation_t *inv) {
+    if (!inv || !inv->mathmap || !inv->mathmap->module_info) return;
+    ModuleInfo *mi = (ModuleInfo *)inv->mathmap->module_info;
+    std::lock_guard<std::mutex> g(mi->mu);
+    for (auto &v : mi->variants) {
+        auto it = v.second.invs.find(inv);
+        if (it == v.second.invs.end()) continue;
+        if (it->second) mmhip_invocation_free(it->second);
+        v.second.invs.erase(it);
+    }
 }
 
 }  // extern "C"

@@ -85,6 +85,7 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
             f->opts.specialize_uservals = 1;
             return f.release();
         }
+        f->ir_json_raw = dump_ir(*f->code);
         if (consts) specialize_constants(*f->code);
         optimize(*f->code);
         analyze_frame_constants(*f->code);
@@ -145,6 +146,7 @@ mmhip_filter *mmhip_filter_new_empty() { return new mmhip_filter(); }
 bool mmhip_filter_finalize(mmhip_filter *f, const KernelOptions &ko, std::string *err) {
     try {
         f->code->filter = f->module.main;
+        if (f->ir_json_raw.empty()) f->ir_json_raw = dump_ir(*f->code);
         optimize(*f->code);
         analyze_frame_constants(*f->code);
         f->kopt = ko;
@@ -185,6 +187,7 @@ int mmhip_filter_userval_info(const mmhip_filter *f, int index, mmhip_userval_in
 }
 
 const char *mmhip_filter_ir_json(mmhip_filter *f) { return f->ir_json.c_str(); }
+const char *mmhip_filter_ir_json_raw(mmhip_filter *f) { return f->ir_json_raw.c_str(); }
 const char *mmhip_filter_kernel_source(mmhip_filter *f) { return f->ks.source.c_str(); }
 int mmhip_filter_num_native_calls(const mmhip_filter *f) { return (int)f->ks.natives.size(); }
 double mmhip_filter_jit_seconds(const mmhip_filter *f) { return f->jit_seconds; }
@@ -304,6 +307,9 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
         inv->images.push_back(d);
     }
     inv->native_maps.assign(f->ks.natives.size(), nullptr);
+    inv->native_map_size.assign(f->ks.natives.size(), {0, 0});
+    inv->native_gen.assign(f->ks.natives.size(), 0);
+    inv->native_memo_deps.assign(f->ks.natives.size(), {});
     inv->native_memo.resize(f->ks.natives.size());
     inv->native_memo_gen.assign(f->ks.natives.size(), 0);
     inv->native_seen.resize(f->ks.natives.size());
@@ -332,6 +338,7 @@ void mmhip_invocation_free(mmhip_invocation *inv) {
     if (inv->stream) (void)hipStreamSynchronize(inv->stream);
     for (void *p : inv->owned) (void)hipFree(p);
     for (void *p : inv->native_maps) if (p) (void)hipFree(p);
+    if (inv->ss_lines) (void)hipFree(inv->ss_lines);
     inv->ws.release();
     if (inv->d_uv) (void)hipFree(inv->d_uv);
     if (inv->d_images) (void)hipFree(inv->d_images);
@@ -438,6 +445,15 @@ int mmhip_set_image_host(mmhip_invocation *inv, int index, const uint8_t *pixels
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, n * 4));
     HIP_TRY(hipMemcpy(d, packed.data(), n * 4, hipMemcpyHostToDevice));
+    // the upload this one replaces (if it was ours) is freed once nothing in flight reads it
+    const void *old = inv->images[inv->image_slot_of_uv[index]].data;
+    for (size_t i = 0; i < inv->owned.size(); ++i)
+        if (inv->owned[i] == old) {
+            (void)hipDeviceSynchronize();     // renders may have been queued on caller streams
+            (void)hipFree(inv->owned[i]);
+            inv->owned.erase(inv->owned.begin() + i);
+            break;
+        }
     inv->owned.push_back(d);
     return mmhip_set_image_device(inv, index, d, width, height);
 }
@@ -596,12 +612,35 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
             want_lo = std::max(0, a.first_row - inv->native_row_margin);
             want_hi = std::min(a.render_height, a.first_row + a.num_rows + inv->native_row_margin);
         }
+        // A map belongs to the render size it was allocated for: the GIMP flow renders a small preview
+        // and then the full image on one invocation (mathmap.c:2191-2223).  On a change the map is
+        // reallocated and everything remembered about it dropped.
+        if (inv->native_maps[k] && (inv->native_map_size[k].first != a.render_width || inv->native_map_size[k].second != a.render_height)) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(inv->native_maps[k]);
+            inv->native_maps[k] = nullptr;
+            inv->native_memo_gen[k] = ~0ULL;
+            inv->native_seen_gen[k] = ~0ULL;
+            inv->native_rows[k] = {0, 0};
+            inv->images[slot].kind = IMG_NULL;
+            inv->images[slot].data = nullptr;
+            table_changed = true;
+        }
+        // generations of the native maps among this call's image arguments (cache.c keys on image ids)
+        std::vector<unsigned long long> deps;
+        for (int i = 0; i < rec.nargs && i < 4; ++i)
+            if (rec.args[i].kind == 2 && rec.args[i].img.idx >= inv->native_slot_base &&
+                rec.args[i].img.idx < inv->native_slot_base + (int)inv->native_gen.size())
+                deps.push_back(inv->native_gen[rec.args[i].img.idx - inv->native_slot_base]);
         if (inv->native_maps[k] && inv->native_memo_gen[k] == inv->input_generation &&
-            memcmp(&inv->native_memo[k], &rec, sizeof rec) == 0 && inv->native_rows[k].first <= want_lo &&
-            inv->native_rows[k].second >= want_hi)
+            memcmp(&inv->native_memo[k], &rec, sizeof rec) == 0 && inv->native_memo_deps[k] == deps &&
+            inv->native_rows[k].first <= want_lo && inv->native_rows[k].second >= want_hi)
             continue;
         size_t bytes = (size_t)a.render_width * a.render_height * 16;
-        if (!inv->native_maps[k]) HIP_TRY(hipMalloc(&inv->native_maps[k], bytes));
+        if (!inv->native_maps[k]) {
+            HIP_TRY(hipMalloc(&inv->native_maps[k], bytes));
+            inv->native_map_size[k] = {a.render_width, a.render_height};
+        }
         std::string err;
         int got_lo = want_lo, got_hi = want_hi;
         NativeDirectOut *dk = (direct.out && (int)k == f->ks.direct_native) ? &direct : nullptr;
@@ -612,7 +651,7 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         const bool whole = a.region_x == 0 && a.region_y == 0 && a.region_width == a.render_width &&
                            a.region_height == a.render_height && a.first_row == 0 && a.num_rows == a.render_height;
         if (dk) {
-            dk->skip_map = whole && !(inv->native_seen_gen[k] == inv->input_generation &&
+            dk->skip_map = whole && !(inv->native_seen_gen[k] == inv->input_generation && inv->native_memo_deps[k] == deps &&
                                       memcmp(&inv->native_seen[k], &rec, sizeof rec) == 0);
             inv->native_seen[k] = rec;
             inv->native_seen_gen[k] = inv->input_generation;
@@ -620,6 +659,8 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         int rc = run_native_filter(f->ks.natives[k].func, rec, inv->images, a.render_width, a.render_height,
                                    (float *)inv->native_maps[k], inv->ws, s, &err, &got_lo, &got_hi, dk);
         if (rc != 0) return fail(err);
+        inv->native_gen[k] = ++inv->native_gen_counter;
+        inv->native_memo_deps[k] = deps;
         if (dk && dk->written) *direct_written = true;
         if (dk && dk->written && dk->skip_map) {       // nothing to memoise, no map to describe
             inv->native_memo_gen[k] = ~0ULL;
@@ -669,7 +710,7 @@ static mmhip_filter *compile_ir_specialized(const mmhip_filter *f, const std::ma
     mmhip_filter *sp = mmhip_filter_new_empty();
     try {
         sp->code.reset(new FilterCode());
-        load_ir_json(sp->module, *sp->code, f->ir_json.c_str());
+        load_ir_json(sp->module, *sp->code, (f->ir_json_raw.empty() ? f->ir_json : f->ir_json_raw).c_str());
         bake_uservals(sp->code->body, consts);
         specialize_constants(*sp->code);
         std::string err;
@@ -687,7 +728,7 @@ static mmhip_filter *compile_ir_specialized(const mmhip_filter *f, const std::ma
 // value set, cached on the filter and on disk through the hiprtc cache).
 static mmhip_filter *active_filter(mmhip_invocation *inv, int frame = 0, float t = 0.0f) {
     mmhip_filter *f = inv->f;
-    if (!f->specialize || !f->ks.natives.empty() || (f->source.empty() && f->ir_json.empty())) return f;
+    if (!f->specialize || !f->ks.natives.empty() || (f->source.empty() && f->ir_json.empty() && f->ir_json_raw.empty())) return f;
     g_err.clear();
     const auto &uvs = f->module.main->uservals;
     std::string key;
@@ -847,8 +888,16 @@ int mmhip_render_supersampled(mmhip_invocation *inv, int frame, float t, int reg
     hipStream_t s = stream ? (hipStream_t)stream : inv->stream;
     const size_t long_bytes = (size_t)(region_w + 1) * bpp * region_h;
     const size_t short_bytes = (size_t)region_w * bpp * region_h;
-    unsigned char *tmp = (unsigned char *)inv->ws.reserve(long_bytes + short_bytes);
-    if (!tmp) return fail("out of device memory for the supersampling lines");
+    // own allocation: the nested renders run native filters, which reallocate inv->ws
+    if (long_bytes + short_bytes > inv->ss_bytes) {
+        if (inv->ss_lines) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(inv->ss_lines); }
+        inv->ss_lines = nullptr;
+        inv->ss_bytes = 0;
+        if (hipMalloc(&inv->ss_lines, long_bytes + short_bytes) != hipSuccess)
+            return fail("out of device memory for the supersampling lines");
+        inv->ss_bytes = long_bytes + short_bytes;
+    }
+    unsigned char *tmp = (unsigned char *)inv->ss_lines;
     const float ox = inv->sampling_offset_x, oy = inv->sampling_offset_y;
     // long slice: region_width + 1 columns, offsets -0.5 (invocation_init_slice, :892)
     inv->sampling_offset_x = -0.5f;

@@ -21,7 +21,9 @@ struct mmhip_filter {
     std::unique_ptr<mm::FilterCode> code;
     mm::KernelOptions kopt;
     mm::KernelSource ks;
-    std::string ir_json;
+    std::string ir_json;        // after the passes: what the kernels were generated from
+    std::string ir_json_raw;    // straight out of lowering (or the importer), before any pass: what the
+                                // oracle prints, so that the passes are tested differentially
     std::vector<char> code_object;
     hipModule_t mod = nullptr;
     hipFunction_t f_pro = nullptr, f_pix = nullptr;
@@ -58,6 +60,15 @@ struct mmhip_invocation {
     bool tables_dirty = true;
     std::vector<void *> owned;             // device buffers we allocated for input images
     std::vector<void *> native_maps;       // float4 maps produced by native filters
+    std::vector<std::pair<int, int>> native_map_size;   // render size native_maps[k] was allocated for
+    // Every recomputation of map k gets a new generation (the reference gives every native result a
+    // new image id, cache.c:65-68); a memo entry records the generations of the native maps among its
+    // image arguments, so a consumer is recomputed when its producer was.
+    std::vector<unsigned long long> native_gen;
+    std::vector<std::vector<unsigned long long>> native_memo_deps;
+    unsigned long long native_gen_counter = 0;
+    void *ss_lines = nullptr;              // the two slices of a supersampled render (own allocation:
+    size_t ss_bytes = 0;                   // native filters reallocate `ws` underneath a nested render)
     std::vector<mm::HNativeRec> native_memo;   // args of the call that produced native_maps[k]
     std::vector<unsigned long long> native_memo_gen;
     std::vector<mm::HNativeRec> native_seen;   // last argument set whose map was asked for (direct output: materialised on its second use)

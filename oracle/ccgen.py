@@ -36,6 +36,19 @@ UNSUPPORTED = {"SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECT
 NOISE_OPS = {"libnoise_perlin", "libnoise_billow", "libnoise_ridged_multi", "libnoise_voronoi"}
 NOISE_LIB = os.path.join(HERE, "_ref", "libmmnoise.so")
 
+# The reference folds every pure op whose arguments are all literals itself, at MathMap compile
+# time, by running the op's macro on the host -- i.e. with glibc (compiler.c:3383-3458
+# constant_folding / the generated fold_rhs; all libm and complex ops are foldable, ops.lisp:88-108).
+# gcc therefore never sees `cexpf(literal)` in the reference's generated C.  This printer does not
+# fold, so gcc would -- with MPFR/MPC, correctly rounded, 1-2 float ulps away from glibc's float
+# complex functions.  Declaring the libm functions non-builtin makes gcc call glibc for them, which
+# is the value the reference's own folding produced.  (sqrt / floor / ceil / fabs / fmod stay builtin:
+# their results are exact or correctly rounded either way.)
+LIBM_NO_BUILTIN = ["-fno-builtin-" + f for f in (
+    "sin cos tan asin acos atan atan2 pow exp log sinh cosh tanh asinh acosh atanh hypot "
+    "csqrtf csinf ccosf ctanf casinf cacosf catanf cexpf clogf cpowf csinhf ccoshf ctanhf casinhf cacoshf "
+    "catanhf cargf cabsf sincos").split()]
+
 
 class OracleUnsupported(Exception):
     pass
@@ -357,13 +370,19 @@ def build_runtime():
 class CpuFilter:
     """A filter compiled by the oracle's cc-equivalent path."""
 
-    def __init__(self, ir_json):
+    def __init__(self, ir_json, extra_cflags=()):
+        """`extra_cflags`: added to the reference's `gcc -O2 -c -fPIC`.  The one use is `-fno-builtin`
+        in tests that compare two printings of one filter where only one of them has literal
+        arguments in libm calls: gcc evaluates `cexpf(literal)` at compile time with MPFR/MPC
+        (correctly rounded), glibc's run-time cexpf is 1-2 ulps off that, so the two would differ
+        by gcc's doing, not the IR's.  (The reference compiles without the flag, and so does every
+        parity check.)"""
         self.ir = json.loads(ir_json) if isinstance(ir_json, str) else ir_json
         gen = Gen(self.ir)
         self.source = gen.source()
         self.nnative = gen.nnative
         noise = [NOISE_LIB, "-Wl,-rpath," + os.path.dirname(NOISE_LIB)] if gen.uses_noise else []
-        key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+        key = hashlib.sha1((self.source + " ".join(LIBM_NO_BUILTIN + list(extra_cflags))).encode()).hexdigest()[:16]
         rt = build_runtime()
         so = os.path.join(BUILD, "f_%s.so" % key)
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in rt):
@@ -372,7 +391,8 @@ class CpuFilter:
             with open(cfile, "w") as f:
                 f.write(self.source)
             # the reference's CGEN_CC / CGEN_LD (Makefile:58-60)
-            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE, "-o", ofile, cfile])
+            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE] + LIBM_NO_BUILTIN + list(extra_cflags) +
+                 ["-o", ofile, cfile])
             _run(["gcc", "-shared", "-o", so + ".tmp", ofile] + rt + noise + ["-lm"])
             os.replace(so + ".tmp", so)
         self.lib = C.CDLL(so)
@@ -383,7 +403,7 @@ class CpuFilter:
 
     def render(self, width, height, uservals=None, images=None, t=0.0, frame=0, intersample=True, threads=1,
                bpp=4, floatmap=False, edge=(0, 0), edge_colors=(0, 0), rows=None, timing=None,
-               region_width=None, sampling_offset=(0.0, 0.0), supersampling=False):
+               region_width=None, sampling_offset=(0.0, 0.0), supersampling=False, render_size=None):
         """Renders on the CPU.  `uservals`: {name: value}; `images`: {name: uint8 [H,W,3|4]}.
         `threads` > 1 splits the rows into contiguous bands like call_invocation_parallel
         (mathmap_common.c:972-1006).  Returns uint8 [H,W,bpp] or float32 [H,W,4]."""
@@ -447,8 +467,13 @@ class CpuFilter:
         dtab = (_ImageDesc * len(descs))(*descs)
         memo = (_Memo * max(self.nnative, 1))()
         a = _Args()
-        a.img_width = a.render_width = a.frame_render_width = width
-        a.img_height = a.render_height = a.frame_render_height = height
+        # `render_size`: a render of the (width x height) canvas at another pixel size -- the GIMP
+        # preview (mathmap.c:2191-2223): img_width/height stay, render_width/height change
+        a.img_width, a.img_height = width, height
+        if render_size is not None:
+            width, height = render_size
+        a.render_width = a.frame_render_width = width
+        a.render_height = a.frame_render_height = height
         a.t, a.frame, a.R = t, frame, np.float32(np.sqrt(2.0))
         a.region_x = a.region_y = 0
         rw = region_width or width

@@ -38,7 +38,7 @@ def main():
             continue
         with open(os.path.join(OUT, stem + ".json.gz"), "wb") as raw:      # mtime=0: reproducible bytes
             with gzip.GzipFile(fileobj=raw, mode="wb", compresslevel=9, mtime=0, filename="") as f:
-                f.write(flt.ir_json.encode())
+                f.write(flt.ir_json_raw.encode())
         manifest.append({"ir": stem + ".json.gz", "golden": golden, "uservals": uv, "needs_image": needs})
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
     print("%d fixtures" % len(manifest))
@@ -61,7 +61,7 @@ def make_example_fixtures():
             flt = flt.specialized()
         with open(os.path.join(out, stem + ".json.gz"), "wb") as raw:
             with gzip.GzipFile(fileobj=raw, mode="wb", compresslevel=9, mtime=0, filename="") as f:
-                f.write(flt.ir_json.encode())
+                f.write(flt.ir_json_raw.encode())
         names.append(stem)
     json.dump(names, open(os.path.join(out, "manifest.json"), "w"), indent=1)
     print("%d example fixtures" % len(names))

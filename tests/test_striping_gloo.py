@@ -21,7 +21,7 @@ WORKER = textwrap.dedent("""
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     w, h = 96, 67                      # odd height: stripes differ by one row
-    cf = CpuFilter(mm.Filter(W.MANDELBROT).ir_json)
+    cf = CpuFilter(mm.Filter(W.MANDELBROT).ir_json_raw)
     lo, hi = stripe_rows(h, rank, world)
     full = cf.render(w, h, rows=(lo, hi))          # only rows [lo,hi) are filled
     stripe = torch.from_numpy(np.ascontiguousarray(full[lo:hi]))
@@ -51,5 +51,5 @@ def test_two_rank_stripes_reassemble(tmp_path):
     import mathmap_amd as mm
     from mathmap_amd import workloads as W
     from oracle.ccgen import CpuFilter
-    want = CpuFilter(mm.Filter(W.MANDELBROT).ir_json).render(96, 67)
+    want = CpuFilter(mm.Filter(W.MANDELBROT).ir_json_raw).render(96, 67)
     assert np.array_equal(np.load(out), want)

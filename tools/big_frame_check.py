@@ -21,7 +21,7 @@ def main():
     out = torch.empty((h, w), dtype=torch.int32, device="cuda")
     inv.render_rows(out.data_ptr(), 0, h)
     inv.sync()
-    cf = CpuFilter(mm.Filter(W.MANDELBROT).ir_json)
+    cf = CpuFilter(mm.Filter(W.MANDELBROT).ir_json_raw)
     for lo in (0, 13333, 26844, 39992):
         want = cf.render(w, h, rows=(lo, lo + 8))[lo:lo + 8]
         got = out[lo:lo + 8].cpu().numpy().view(np.uint8).reshape(8, w, 4)
@@ -41,7 +41,7 @@ def main():
     out = torch.empty((h, w), dtype=torch.int32, device="cuda")
     inv.render_rows(out.data_ptr(), 0, h)
     inv.sync()
-    cf = CpuFilter(flt.ir_json)
+    cf = CpuFilter(flt.ir_json_raw)
     for lo in (0, 16383, 29999, h - 8):
         got = out[lo:lo + 8].cpu().numpy().view(np.uint8).reshape(8, w, 4)
         want = cf.render(w, h, images={"in": img}, rows=(lo, lo + 8))[lo:lo + 8]

@@ -40,7 +40,7 @@ def main():
                 if not np.array_equal(outs[0], outs[1]):
                     bad.append((seed, variant, "spec != generic"))
                     continue
-                want = CpuFilter(mm.Filter(src, **opts).ir_json).render(
+                want = CpuFilter(mm.Filter(src, **opts).ir_json_raw).render(
                     w, h, uservals=uv, images={n: imgs[n] for n in names}, t=0.4,
                     intersample=opts.get("intersample", True), edge=(opts.get("edge_x", 0), opts.get("edge_y", 0)))
                 d = np.abs(outs[0].astype(int) - want.astype(int))

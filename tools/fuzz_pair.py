@@ -22,7 +22,7 @@ def main():
         src = make_filter_arith(seed)
         uv = {"k": seed % 9, "m": 0.1 + (seed % 7) * 0.3}
         try:
-            want = CpuFilter(mm.Filter(src).ir_json).render(w, h, uservals=uv, t=0.6)
+            want = CpuFilter(mm.Filter(src).ir_json_raw).render(w, h, uservals=uv, t=0.6)
             for spec in (False, True):
                 flt = mm.Filter(src, specialize=spec)
                 paired += "const mm_pf mm_y2" in flt.kernel_source

@@ -19,6 +19,6 @@ for name, src in srcs.items():
             flt = mm.Filter(src, intersample=inter, edge_x=ex, edge_y=ey)
             inv = flt.invoke(w, h); inv.set_image("in", img); inv.set_edge_colors(*colors)
             got = inv.render()
-            want = CpuFilter(flt.ir_json).render(w, h, images={"in": img}, intersample=inter, edge=(ex, ey), edge_colors=colors)
+            want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, intersample=inter, edge=(ex, ey), edge_colors=colors)
             d = np.abs(got.astype(int) - want.astype(int))
             print(name, "bilinear" if inter else "nearest", (ex, ey), "max", d.max(), "n", (d > 0).sum(), flush=True)

@@ -17,7 +17,7 @@ for (w, h) in [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (17, 2), (255, 3)]:
             for k, v in uv.items(): inv.set(k, v)
             if needs: inv.set_image("in", np.ascontiguousarray(img))
             got = inv.render(t=0.2)
-            want = CpuFilter(flt.ir_json).render(w, h, uservals=uv, images={"in": np.ascontiguousarray(img)} if needs else {}, t=0.2)
+            want = CpuFilter(flt.ir_json_raw).render(w, h, uservals=uv, images={"in": np.ascontiguousarray(img)} if needs else {}, t=0.2)
             d = np.abs(got.astype(int) - want.astype(int)).max()
             if d > 1: bad.append((w, h, name, int(d)))
         except Exception as e:
