@@ -1,12 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mpixels/s of examples/Render/Mandelbrot at 8192x8192 on MI355X.
+"""Headline benchmark: Mpixels/s of the per-pixel path on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run,
-one rank per GPU).  A step = one full frame of the hot path (prologue + pixel kernel) per
-rank; frames of an animation are independent, so ranks never communicate on the data path
-(weak scaling).  Prints one JSON line on rank 0.
+one rank per GPU).  A step = one full frame of the hot path (prologue + pixel kernel) per rank;
+frames of an animation are independent, so ranks never communicate on the data path (weak
+scaling; `--mode stripes` row-stripes every frame across the ranks instead: strong scaling,
+BASELINE config 5).  Rank 0 prints ONE JSON line.
+
+BASELINE.json's metric is "Mpixels/sec (Mandelbrot & Droste @8192x8192)": `value` is the
+Mandelbrot frame rate (config 1, the configuration the >= 100x target is quoted on); the Droste
+half (config 2: defaults and -DNoTransparency=1) rides in the same line under "droste", each with
+its own kernel time, rate, HBM fraction, verification and CPU baseline.  After the timed region
+sampled row bands of the last timed frame are compared with the CPU oracle ("verified").
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -16,7 +25,220 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PIXEL = {"mandelbrot": 4, "droste": 8, "pond": 8, "ident": 8, "gauss": 104}
-HBM_PEAK_GBS = 8000.0
+GAUSS_FUSED_FLOOR_BYTES = 40            # render fused into pass 1, pack into pass 2
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md
+F32_VECTOR_PEAK_TF = 157.3              # MI355X_MICROARCH.md, FMA counted as 2; exact-rounding code cannot fuse: 78.6
+NUM_FRAMES = 120                        # BASELINE config 5: 120-frame animation
+
+
+def frame_t(frame):
+    """t of animation frame `frame` as the CLI computes it: (float)frame / (float)num_frames
+    (mathmap_cmdline.c:835)."""
+    import numpy as np
+    return float(np.float32(frame % NUM_FRAMES) / np.float32(NUM_FRAMES))
+
+
+def device_image(torch, w, h):
+    """Synthetic RGBA8 input generated directly in HBM (packed 0xRRGGBBAA, alpha 255)."""
+    yy = torch.arange(h, device="cuda", dtype=torch.int64).view(h, 1)
+    xx = torch.arange(w, device="cuda", dtype=torch.int64).view(1, w)
+    chans = []
+    for c in range(3):
+        v = ((xx * (131 + 17 * c) + yy * (71 + 29 * c) + (977 + c * 17)) ^ ((xx * yy) >> 3)) & 63
+        g = (xx * 255 // max(w - 1, 1) + yy * 255 // max(h - 1, 1)) // 2
+        chans.append(((v + (g * 3) // 4) & 255))
+    packed = ((chans[0] << 24) | (chans[1] << 16) | (chans[2] << 8) | 255) & 0xFFFFFFFF
+    img = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
+    return img
+
+
+def host_image_rows(torch, dev_img, lo, hi):
+    """Rows [lo, hi) of the device image as uint8 [rows, W, 3] (what the oracle reads)."""
+    import numpy as np
+    p = dev_img[lo:hi].cpu().numpy().view(np.uint32)
+    return np.stack([(p >> 24) & 255, (p >> 16) & 255, (p >> 8) & 255], axis=-1).astype(np.uint8)
+
+
+class Workload:
+    """One filter bound to a frame size, an input and user values, rendering into HBM."""
+
+    def __init__(self, mm, W, torch, name, size, uservals=None, specialize=True, tile_w=0, dev_img=None):
+        self.name, self.w, self.h = name, size, size
+        self.torch = torch
+        self.src = W.ALL["gauss_direct" if name == "gauss" else name]
+        self.uservals = dict(uservals or {})
+        self.specialize = bool(specialize)
+        if name == "gauss":
+            sigma = 20.0 / ((size - 1) / 2.0)          # 20 px (gauss.c:659-660: sigma_px = |dev * (W-1)/2|)
+            self.uservals.update(hdev=sigma, vdev=sigma)
+        self.flt = mm.Filter(self.src, tile_w=tile_w, specialize=specialize)
+        t0 = time.perf_counter()
+        self.inv = self.flt.invoke(size, size)
+        self.needs_image = "image in" in self.src
+        self.dev_img = dev_img
+        if self.needs_image:
+            if self.dev_img is None:
+                self.dev_img = device_image(torch, size, size)
+            self.inv.set_image_device("in", self.dev_img.data_ptr(), size, size, keepalive=self.dev_img)
+        for k, v in self.uservals.items():
+            self.inv.set(k, v)
+        self.jit_seconds = time.perf_counter() - t0
+        self.out = torch.empty((size, size, 4), dtype=torch.uint8, device="cuda")
+        self.inv.enable_timing(True)
+
+    def render(self, frame, stream, rows=None, out=None):
+        lo, hi = rows or (0, self.h)
+        if self.name == "gauss":
+            # a new input generation per frame, otherwise the native-filter memo
+            # (native-filters/cache.c semantics) would hand back the previous frame's map
+            self.inv.set_image_device("in", self.dev_img.data_ptr(), self.w, self.h)
+        o = self.out if out is None else out
+        self.inv.render_rows(o.data_ptr() + lo * self.w * 4, lo, hi, t=frame_t(frame), frame=0, stream=stream)
+
+    def oracle(self):
+        from oracle.ccgen import CpuFilter
+        return CpuFilter(self.flt.ir_json_raw)
+
+    def host_images(self):
+        """The whole input on the host for the oracle (uint8 [H, W, 3])."""
+        if not self.needs_image:
+            return {}
+        return {"in": host_image_rows(self.torch, self.dev_img, 0, self.h)}
+
+    def verify(self, frame, bands=6, rows_per_band=4, images=None):
+        """Sampled row bands of `self.out` (frame `frame`) against the CPU oracle; returns
+        {"ok", "max_diff", "n_diff", "n_gt1", "pixels"}.  ok: <= 1 LSB everywhere (the north-star bar);
+        the blur must be exact."""
+        import numpy as np
+        h, w = self.h, self.w
+        starts = sorted({0, h - rows_per_band} | {int((h - rows_per_band) * (k + 0.41) / max(bands - 2, 1)) for k in range(bands - 2)})
+        if self.name == "gauss":
+            from oracle.ccgen import gauss_rows
+            rows = sorted({r for s in starts for r in range(s, s + rows_per_band)})
+            img = (images or self.host_images())["in"]
+            dev = np.float32(self.uservals["hdev"])
+            threads = max(1, min(16, len(os.sched_getaffinity(0))))
+            fm = gauss_rows(img, dev, dev, rows, threads=threads)
+            c = np.where(fm > 0, np.minimum(fm, np.float32(1.0)), np.float32(0.0)).astype(np.float64)
+            want = (c * 255.0).astype(np.uint8)
+            got = self.out[rows].cpu().numpy()
+            d = np.abs(got.astype(int) - want.astype(int))
+            return {"ok": bool(d.max() == 0), "max_diff": int(d.max()), "n_diff": int((d > 0).sum()), "n_gt1": int((d > 1).sum()),
+                    "pixels": int(len(rows) * w), "against": "oracle.gauss_rows: full CPU vertical pass, sampled rows"}
+        cf = self.oracle()
+        images = images if images is not None else self.host_images()
+        mx = nd = n1 = 0
+        for lo in starts:
+            want = cf.render(w, h, uservals=self.uservals, images=images, rows=(lo, lo + rows_per_band), t=frame_t(frame))
+            got = self.out[lo:lo + rows_per_band].cpu().numpy()
+            d = np.abs(got.astype(int) - want[lo:lo + rows_per_band].astype(int))
+            mx, nd, n1 = max(mx, int(d.max())), nd + int((d > 0).sum()), n1 + int((d > 1).sum())
+        return {"ok": bool(mx <= 1 and n1 == 0), "max_diff": mx, "n_diff": nd, "n_gt1": n1,
+                "pixels": int(len(starts) * rows_per_band * w), "against": "oracle (pre-pass IR, gcc -O2, glibc), sampled row bands"}
+
+    def kernel_key(self):
+        """Identifies the kernel text that ran (the specialised variant when there is one)."""
+        try:
+            f = self.flt
+            if self.specialize and self.name != "gauss":        # filters with native calls keep the generic kernel
+                f = self.flt.specialized(self.uservals)
+            return hashlib.sha1(f.kernel_source.encode()).hexdigest()[:16]
+        except Exception:
+            return None
+
+
+def timed_frames(torch, wl, steps, warmup, stream):
+    """W untimed + K timed frames queued back to back; returns (elapsed_s, mean kernel ms)."""
+    import numpy as np
+    for i in range(warmup):
+        wl.render(i, stream)
+    torch.cuda.synchronize()
+    wl.inv.drain_kernel_ms()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wl.render(i, stream)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return el, float(np.mean(wl.inv.drain_kernel_ms()))
+
+
+def pmc_traffic(workload, size, kernel_key):
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, tools/pmc_traffic.py): bench.py cannot run the profiler around itself.  A summary
+    only counts when it was collected for this very kernel text (its `kernel_key`); otherwise null,
+    with the reason."""
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s%d.json" % (workload, size)))):
+        try:
+            j = json.load(open(fn))
+        except Exception:
+            continue
+        best = (fn, j)
+    if not best:
+        return None, {"file": None, "why": "no PMC summary committed for this workload / size"}
+    fn, j = best
+    src = {"file": os.path.relpath(fn, ROOT), "collected_for_kernel_key": j.get("kernel_key"), "kernel_key_now": kernel_key,
+           "collected_at_commit": j.get("commit")}
+    if workload != "gauss" and (j.get("kernel_key") is None or j.get("kernel_key") != kernel_key):
+        src["why"] = "stale: collected for another kernel text"
+        return None, src
+    return j.get("traffic_bytes_per_launch"), src
+
+
+def cpu_baseline_bands(cf, w, h, uservals, images, cores, rows_one=512, frame=0):
+    """The oracle (cc-equivalent C, gcc -O2) on a bounded sample of the same frame: `nb` bands spread
+    evenly over the frame height, so the sample sees the same mix of cheap and expensive rows."""
+    def timed(threads, nb, bh):
+        starts = [int((h - bh) * (k + 0.5) / nb) for k in range(nb)]
+        tot = 0.0
+        for lo in starts:
+            tm = []
+            cf.render(w, h, uservals=uservals, images=images, rows=(lo, lo + bh), threads=threads, timing=tm, t=frame_t(frame))
+            tot += tm[0]
+        return w * bh * nb / 1e6 / tot
+    nb, bh = 16, max(1, rows_one // 16)
+    one = timed(1, nb, bh)
+    many = timed(cores, 4, 16 * cores)
+    return {"value": one, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "%d bands of %d rows spread over the same %dx%d frame; oracle cc-equivalent C (gcc -O2 -fPIC), "
+                      "1 thread like the reference CLI (mathmap_cmdline.c:844)" % (nb, bh, w, h),
+            "all_cores": {"value": many, "cores": cores,
+                          "note": "4 bands of %d rows, row-band threads like the reference GIMP path "
+                                  "(mathmap_common.c:972-1006)" % (16 * cores)}}
+
+
+def host_delivered_rate(torch, wl, steps):
+    """the metric ends at "the last byte of q written on the host".  Frames rendered into
+    two device buffers in turn; frame i's device-to-host copy (pinned destination, its own stream)
+    overlaps the kernel of frame i+1.  PCIe-inclusive: reported beside `value`, never as it."""
+    w, h = wl.w, wl.h
+    outs = [torch.empty((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    host = [torch.empty((h, w, 4), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    comp, copy = torch.cuda.Stream(), torch.cuda.Stream()
+    done = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+
+    def run(n):
+        for i in range(n):
+            b = i & 1
+            if i >= 2:
+                comp.wait_event(copied[b])           # the buffer's previous frame has left
+            wl.render(i, comp.cuda_stream, out=outs[b])
+            done[b].record(comp)
+            copy.wait_event(done[b])
+            with torch.cuda.stream(copy):
+                host[b].copy_(outs[b], non_blocking=True)
+            copied[b].record(copy)
+        torch.cuda.synchronize()
+    run(3)
+    t0 = time.perf_counter()
+    run(steps)
+    el = time.perf_counter() - t0
+    same = bool(torch.equal(host[(steps - 1) & 1], outs[(steps - 1) & 1].cpu()))
+    return {"value": w * h * steps / 1e6 / el, "unit": "Mpixels/s", "ms_per_frame": el / steps * 1e3,
+            "achieved_pcie_GBs": w * h * 4 * steps / el / 1e9, "frames": steps, "host_copy_equals_device_frame": same,
+            "note": "pinned host buffer, D2H of frame i overlapped with the kernel of frame i+1 (two device buffers, "
+                    "two streams); bound by the copy, not the kernel"}
 
 
 def main():
@@ -27,11 +249,14 @@ def main():
     ap.add_argument("--workload", default="mandelbrot", choices=sorted(ALGO_BYTES_PER_PIXEL))
     ap.add_argument("--size", type=int, default=0, help="frame edge in pixels (default 8192; 16384 for gauss)")
     ap.add_argument("--tile-w", type=int, default=0)
+    ap.add_argument("-D", dest="defs", action="append", default=[], metavar="name=value", help="user value, like the CLI's -D")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="frames", choices=["frames", "stripes"],
                     help="multi-GPU decomposition: one whole frame per rank and step (weak scaling, default) or every "
                          "frame row-striped across the ranks (strong scaling; BASELINE config 5)")
-    ap.add_argument("--no-generic", action="store_true", help="skip the generic-kernel comparison (for profiling runs)")
+    ap.add_argument("--no-generic", action="store_true", help="skip the generic-kernel comparison")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="profiling runs: only the timed region (no verification, Droste, host-delivered rate, CPU baseline)")
     ap.add_argument("--specialize", type=int, default=1,
                     help="1 = user-value specialising JIT (default), 0 = generic kernel reading user values at run time")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
@@ -51,53 +276,26 @@ def main():
 
     import mathmap_amd as mm
     from mathmap_amd import workloads as W
+    from mathmap_amd.striping import stripe_rows
     mm.set_device(local_rank)                  # the library's own handle on the rank's GPU (one process per GPU)
 
-    w = h = args.size or (16384 if args.workload == "gauss" else 8192)
-    src = W.ALL["gauss_direct" if args.workload == "gauss" else args.workload]
-    flt = mm.Filter(src, tile_w=args.tile_w, specialize=bool(args.specialize))
-    t0 = time.perf_counter()
-    inv = flt.invoke(w, h)
-    jit_s = time.perf_counter() - t0
-    needs_image = "image in" in src
-    dev_img = None
-    if needs_image:
-        # synthetic RGBA8 input generated directly in HBM (packed 0xRRGGBBAA, alpha 255)
-        yy = torch.arange(h, device="cuda", dtype=torch.int64).view(h, 1)
-        xx = torch.arange(w, device="cuda", dtype=torch.int64).view(1, w)
-        chans = []
-        for c in range(3):
-            v = ((xx * (131 + 17 * c) + yy * (71 + 29 * c) + (977 + c * 17)) ^ ((xx * yy) >> 3)) & 63
-            g = (xx * 255 // max(w - 1, 1) + yy * 255 // max(h - 1, 1)) // 2
-            chans.append(((v + (g * 3) // 4) & 255))
-        packed = (chans[0] << 24) | (chans[1] << 16) | (chans[2] << 8) | 255
-        dev_img = (packed & 0xFFFFFFFF).to(torch.int64)
-        dev_img = torch.where(dev_img >= 2 ** 31, dev_img - 2 ** 32, dev_img).to(torch.int32).contiguous()
-        del chans, packed, xx, yy
-        inv.set_image_device("in", dev_img.data_ptr(), w, h, keepalive=dev_img)
-    if args.workload == "gauss":
-        sigma = 20.0 / ((w - 1) / 2.0)     # 20 px (gauss.c:659-660: sigma_px = |dev * (W-1)/2|)
-        inv.set("hdev", sigma)
-        inv.set("vdev", sigma)
-    out = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    size = args.size or (16384 if args.workload == "gauss" else 8192)
+    uv = {}
+    for d in args.defs:
+        k, v = d.split("=", 1)
+        uv[k] = float(v)
+    wl = Workload(mm, W, torch, args.workload, size, uv, bool(args.specialize), args.tile_w)
+    w = h = size
     stream = torch.cuda.current_stream().cuda_stream
-    inv.enable_timing(True)
-
-    from mathmap_amd.striping import stripe_rows
     stripes = args.mode == "stripes" and world > 1
     row_lo, row_hi = stripe_rows(h, rank, world) if stripes else (0, h)
     if stripes:
-        inv.set_native_row_margin(0)          # a blur stripe computes its own rows + halo locally
+        wl.inv.set_native_row_margin(0)          # a blur stripe computes its own rows + halo locally
 
     def step(i):
-        # frames mode: one animation frame per rank and step (frame index i*world+rank, t = frame/120);
+        # frames mode: one animation frame per rank and step (frame i*world+rank of the 120-frame animation);
         # stripes mode: every rank renders its row stripe of frame i
-        fr = i if stripes else i * world + rank
-        if args.workload == "gauss":
-            # a new input generation per frame, otherwise the native-filter memo
-            # (native-filters/cache.c semantics) would reuse the blurred map
-            inv.set_image_device("in", dev_img.data_ptr(), w, h)
-        inv.render_rows(out.data_ptr() + row_lo * w * 4, row_lo, row_hi, t=(fr % 120) / 120.0, frame=0, stream=stream)
+        wl.render(i if stripes else i * world + rank, stream, rows=(row_lo, row_hi))
 
     for i in range(args.warmup):
         step(i)
@@ -106,7 +304,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    inv.drain_kernel_ms()                        # forget the warm-up launches
+    wl.inv.drain_kernel_ms()                     # forget the warm-up launches
     for i in range(args.steps):
         step(i)                                  # queued back to back: no synchronisation per step
     torch.cuda.synchronize()
@@ -114,120 +312,158 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    my_kernel_ms = float(np.mean(wl.inv.drain_kernel_ms()))   # HIP events on the launch stream around every launch
+    per_rank_ms = [my_kernel_ms]
     if world > 1:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        ks = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ks, torch.tensor([my_kernel_ms], device="cuda", dtype=torch.float64))
+        per_rank_ms = [float(k.item()) for k in ks]
 
     if rank == 0:
+        last_frame = (args.steps - 1) if stripes else (args.steps - 1) * world + rank
         mpix = w * h * args.steps * (1 if stripes else world) / 1e6
         value = mpix / elapsed
-        kernel_ms = inv.drain_kernel_ms()        # HIP events recorded on the launch stream around every launch
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = my_kernel_ms
         if args.workload == "gauss":
-            k_ms = elapsed / args.steps * 1e3     # whole chain: render + 4 scan kernels + sample/pack
+            k_ms = elapsed / args.steps * 1e3     # whole chain: 4 scan kernels (render fused into the first, pack into the last)
         bpp = ALGO_BYTES_PER_PIXEL[args.workload]
-        achieved = w * h * bpp / (k_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, summarised by tools/pmc_traffic.py into profiles/): bench.py cannot run the
-        # profiler around itself, so it reports the committed per-launch figure for this
-        # exact workload/size, or null when none has been collected.
-        traffic = None
-        import glob
-        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s%d.json" % (args.workload, w)))):
-            try:
-                traffic = json.load(open(fn)).get("traffic_bytes_per_launch")
-            except Exception:
-                pass
+        px_per_launch = w * (row_hi - row_lo)
+        hbm_achieved = px_per_launch * bpp / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload, w, wl.kernel_key())
+        names = {"mandelbrot": "examples/Render/Mandelbrot", "droste": "examples/Map/Droste", "pond": "examples/Distorts/Pond",
+                 "ident": "examples/Utilities/Ident", "gauss": "native-filters gauss sigma=20 px (examples/Blur/Gaussian Blur shape)"}
         res = {
             "metric": "Mpixels/sec (%s @%dx%d)" % (args.workload, w, h),
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if stripes else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "examples/Render/Mandelbrot 8192x8192, defaults (num_iterations=32), RGBA8 out"
-                       if args.workload == "mandelbrot" else "%s %dx%d" % (args.workload, w, h),
+            "config": {"workload": "%s %dx%d, %s, RGBA8 out, frames of the %d-frame animation (t = frame/%d)"
+                                   % (names[args.workload], w, h,
+                                      "defaults (num_iterations=32)" if args.workload == "mandelbrot" and not uv
+                                      else ("-D" + " -D".join("%s=%g" % kv for kv in sorted(uv.items())) if uv else "defaults"),
+                                      NUM_FRAMES, NUM_FRAMES),
                        "frames_per_step_per_gpu": (1.0 / world) if stripes else 1,
                        "parallelism": ("row stripes x %d of one frame (no data-path collective)" if stripes
                                        else "frames x %d (no data-path collective)") % world,
-                       "jit_seconds": round(jit_s, 3)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gaussian_blur chain: 2x(k_iir_causal, k_iir_anticausal_T), render_image fused into the first pass, the RGBA8 pack into the last"
-                         if args.workload == "gauss" else "mm_pixels",
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_pixel": bpp},
+                       "jit_seconds": round(wl.jit_seconds, 3)},
+            "per_rank_kernel_ms": per_rank_ms,
         }
+        hbm = {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_pixel": bpp}
+        kernel_name = ("gaussian_blur chain: 2x(k_iir_causal, k_iir_anticausal_T), render_image fused into the first pass, "
+                       "the RGBA8 pack into the last") if args.workload == "gauss" else "mm_pixels"
         if args.workload == "mandelbrot":
-            # compute-side view (the kernel writes 4 B/px and reads nothing, so HBM is not its
-            # bound): iterations are recovered exactly from the grey level n/32
-            n_iter = torch.round(out[:, :, 0].to(torch.float32) * (32.0 / 255.0)).sum().item()
-            flops = n_iter * 10.0     # per iteration: 5 mul + 5 add/sub on the complex plane (j,k parts are 0)
-            res["valu"] = {"pixel_iterations_per_launch": n_iter, "useful_flops_per_launch": flops,
-                           "achieved_tflops": flops / (k_ms * 1e-3) / 1e12, "peak_tflops_f32_no_fma": 78.6,
-                           "note": "exact-rounding code cannot use FMA, so the peak is half the 157.3 TF vector peak"}
-        if world == 1 and args.specialize and not args.no_generic and args.workload != "gauss":
-            # the generic kernel (user values read at run time) on the same frame: must be
-            # byte-identical; its rate is reported beside the specialised one
-            g_flt = mm.Filter(src, tile_w=args.tile_w, specialize=False)
-            g_inv = g_flt.invoke(w, h)
-            if needs_image:
-                g_inv.set_image_device("in", dev_img.data_ptr(), w, h, keepalive=dev_img)
+            # The kernel writes 4 B/px and reads nothing: it is bound by vector-ALU issue, not HBM.  Iterations are
+            # recovered exactly from the grey level n/32; per iteration 5 mul + 5 add/sub on the complex plane
+            # (the j,k parts are identically 0 for the default parameters).
+            n_iter = torch.round(wl.out[row_lo:row_hi, :, 0].to(torch.float32) * (32.0 / 255.0)).sum().item()
+            flops = n_iter * 10.0
+            tf = flops / (k_ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "valu", "achieved": tf, "peak": F32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tf / F32_VECTOR_PEAK_TF, "frac_of_no_fma_peak": tf / (F32_VECTOR_PEAK_TF / 2),
+                               "note": "useful f32 flops; the reference's arithmetic rounds after every operation, so FMA "
+                                       "(half of the 157.3 TF vector peak) is not available to it",
+                               "pixel_iterations_per_launch": n_iter, "useful_flops_per_launch": flops,
+                               "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "kernel_ms": k_ms,
+                               "hbm": hbm}
+        else:
+            res["roofline"] = dict(hbm, bound="hbm", traffic=traffic, traffic_source=traffic_src, kernel=kernel_name,
+                                   kernel_ms=k_ms)
             if args.workload == "gauss":
-                g_inv.set("hdev", sigma)
-                g_inv.set("vdev", sigma)
-            g_out = torch.empty_like(out)
-            g_inv.enable_timing(True)
-            gms = []
-            step(args.steps - 1)     # re-render the last timed frame for the comparison
-            torch.cuda.synchronize()
-            for i in range(3):
-                g_inv.render_rows(g_out.data_ptr(), 0, h, t=(((args.steps - 1) * world + rank) % 120) / 120.0, stream=stream)
-                gms.append(g_inv.last_kernel_ms())
-            torch.cuda.synchronize()
-            res["generic_kernel"] = {"kernel_ms": float(np.mean(gms[1:])), "value": w * h / 1e6 / (float(np.mean(gms[1:])) * 1e-3),
-                                     "byte_identical_to_specialised": bool(torch.equal(g_out, out))}
-        if not args.no_cpu_baseline and world == 1:
-            from oracle.ccgen import CpuFilter
-            cf = CpuFilter(flt.ir_json)
-            cw = w
-            if args.workload == "gauss":
-                cw = min(w, 2048)          # the CPU blur is timed on a smaller square frame (work is linear in pixels)
-            images = {"in": W.synthetic_image(cw, cw)} if needs_image else {}
+                floor = px_per_launch * GAUSS_FUSED_FLOOR_BYTES / (k_ms * 1e-3) / 1e9
+                res["roofline"]["fused_floor"] = {"algorithmic_bytes_per_pixel": GAUSS_FUSED_FLOOR_BYTES, "achieved": floor,
+                                                  "frac": floor / HBM_PEAK_GBS,
+                                                  "note": "SURVEY 8(d): 104 B/px is the unfused chain, 40 B/px the floor with render "
+                                                          "fused into pass 1 and pack into pass 2 (what this implementation does)"}
+        if args.no_extras or world > 1:
+            print(json.dumps(res))
+        else:
+            images = wl.host_images()
+            # ---- verification of the last timed frame against the oracle (after the timed region) ----
+            res["verified"] = False
+            try:
+                v = wl.verify(last_frame, images=images)
+                res["verified"] = v["ok"]
+                res["verification"] = v
+            except Exception as e:      # a verification that cannot run is a failed verification
+                res["verification"] = {"ok": False, "error": repr(e)[:300]}
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             cores = max(1, min(cores, 16))     # the GPU box grants 16 host cores per GPU
-            if args.workload == "gauss":
-                uv = {"hdev": 20.0 / ((cw - 1) / 2.0), "vdev": 20.0 / ((cw - 1) / 2.0)}
-                tm = []
-                cf.render(cw, cw, uservals=uv, images=images, threads=1, timing=tm)
-                one = cw * cw / 1e6 / tm[0]
-                res["cpu_baseline"] = {
-                    "value": one, "unit": "Mpixels/s", "cores": 1, "kind": "port",
-                    "sample": "whole %dx%d frame, sigma 20 px: render_image + gauss_iir (both passes) + sample/pack; "
-                              "oracle C restatement of native-filters/gauss.c, gcc -O2, 1 thread (the reference's "
-                              "gauss is single-threaded)" % (cw, cw)}
-            else:
-                # bounded sample: `nb` bands of `bh` rows spread evenly over the frame height, so the
-                # sample sees the same mix of cheap and expensive rows as the whole frame
-                def timed(threads, nb, bh):
-                    starts = [int((h - bh) * (k + 0.5) / nb) for k in range(nb)]
-                    tot = 0.0
-                    for lo in starts:
-                        tm = []
-                        cf.render(w, h, images=images, rows=(lo, lo + bh), threads=threads, timing=tm)
-                        tot += tm[0]
-                    return w * bh * nb / 1e6 / tot
-                nb, bh = 16, max(1, (args.cpu_rows or 512) // 16)
-                one = timed(1, nb, bh)
-                many = timed(cores, 4, 64 * cores)
-                res["cpu_baseline"] = {
-                    "value": one, "unit": "Mpixels/s", "cores": 1, "kind": "port",
-                    "sample": "%d bands of %d rows spread over the same %dx%d frame; oracle cc-equivalent C "
-                              "(gcc -O2 -fPIC), 1 thread like the reference CLI (mathmap_cmdline.c:844)" % (nb, bh, w, h),
-                    "all_cores": {"value": many, "cores": cores,
-                                  "note": "4 bands of %d rows, row-band threads like the reference GIMP path "
-                                          "(mathmap_common.c:972-1006)" % (64 * cores)},
-                }
-            res["gpu_over_cpu_1thread"] = value / res["cpu_baseline"]["value"]
-        print(json.dumps(res))
+            if args.specialize and not args.no_generic and args.workload != "gauss":
+                # the generic kernel (user values read at run time) on the same frame: must be byte-identical
+                g = Workload(mm, W, torch, args.workload, size, uv, False, args.tile_w, dev_img=wl.dev_img)
+                gms = []
+                for i in range(3):
+                    g.render(last_frame, stream)
+                    gms.append(g.inv.last_kernel_ms())
+                torch.cuda.synchronize()
+                wl.render(last_frame, stream)
+                torch.cuda.synchronize()
+                res["generic_kernel"] = {"kernel_ms": float(np.mean(gms[1:])), "value": w * h / 1e6 / (float(np.mean(gms[1:])) * 1e-3),
+                                         "byte_identical_to_specialised": bool(torch.equal(g.out, wl.out))}
+                del g
+            if not args.no_cpu_baseline:
+                if args.workload == "gauss":
+                    from oracle.ccgen import CpuFilter
+                    cw = min(w, 2048)          # the CPU blur is timed on a smaller square frame (work is linear in pixels)
+                    cuv = {"hdev": 20.0 / ((cw - 1) / 2.0), "vdev": 20.0 / ((cw - 1) / 2.0)}
+                    tm = []
+                    CpuFilter(wl.flt.ir_json).render(cw, cw, uservals=cuv, images={"in": W.synthetic_image(cw, cw)}, threads=1, timing=tm)
+                    res["cpu_baseline"] = {
+                        "value": cw * cw / 1e6 / tm[0], "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                        "sample": "whole %dx%d frame, sigma 20 px: render_image + gauss_iir (both passes) + sample/pack; oracle C "
+                                  "restatement of native-filters/gauss.c, gcc -O2, 1 thread (the reference's gauss is "
+                                  "single-threaded)" % (cw, cw)}
+                else:
+                    from oracle.ccgen import CpuFilter
+                    # timed on the IR after the passes (frame constants hoisted into init_frame, like the reference's
+                    # own xy-const slice): the faster, fairer CPU figure
+                    res["cpu_baseline"] = cpu_baseline_bands(CpuFilter(wl.flt.ir_json), w, h, wl.uservals, images, cores,
+                                                             rows_one=args.cpu_rows or 512, frame=last_frame)
+                res["gpu_over_cpu_1thread"] = value / res["cpu_baseline"]["value"]
+            # ---- the metric's second workload: Droste 8192^2, defaults and NoTransparency=1 ----
+            if args.workload == "mandelbrot":
+                res["droste"] = {}
+                dimg = None
+                dhost = None
+                for label, duv in (("defaults", {}), ("NoTransparency=1", {"NoTransparency": 1})):
+                    try:
+                        d = Workload(mm, W, torch, "droste", 8192, duv, bool(args.specialize), args.tile_w, dev_img=dimg)
+                        dimg = d.dev_img
+                        if dhost is None:
+                            dhost = d.host_images()
+                        el, kms = timed_frames(torch, d, max(5, args.steps // 2), max(2, args.warmup), stream)
+                        nfr = max(5, args.steps // 2)
+                        ach = 8192 * 8192 * 8 / (kms * 1e-3) / 1e9
+                        tr, trs = pmc_traffic("droste" if not duv else "droste_nt", 8192, d.kernel_key())
+                        ent = {"kernel_ms": kms, "value": 8192 * 8192 * nfr / 1e6 / el, "unit": "Mpixels/s", "frames": nfr,
+                               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_pixel": 8, "traffic": tr,
+                                            "traffic_source": trs, "kernel": "mm_pixels",
+                                            "note": "8 B/px compulsory (4 read + 4 written); the kernel is bound by VALU issue "
+                                                    "(complex log/exp chain), see profiles/*sq_counters_droste*"}}
+                        v = d.verify(nfr - 1, images=dhost)
+                        ent["verified"] = v["ok"]
+                        ent["verification"] = v
+                        if not args.no_cpu_baseline:
+                            from oracle.ccgen import CpuFilter
+                            ent["cpu_baseline"] = cpu_baseline_bands(CpuFilter(d.flt.ir_json), 8192, 8192, duv, dhost, cores,
+                                                                     rows_one=128, frame=nfr - 1)
+                            ent["gpu_over_cpu_1thread"] = ent["value"] / ent["cpu_baseline"]["value"]
+                        res["droste"][label] = ent
+                        del d
+                    except Exception as e:
+                        res["droste"][label] = {"error": repr(e)[:300]}
+                del dimg, dhost
+            # ---- host-delivered rate (PCIe-inclusive; never `value`) ----
+            try:
+                res["host_delivered"] = host_delivered_rate(torch, wl, max(4, min(args.steps, 12)))
+            except Exception as e:
+                res["host_delivered"] = {"error": repr(e)[:300]}
+            print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 

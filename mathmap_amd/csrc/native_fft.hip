@@ -275,8 +275,8 @@ int fft_native_filter(const std::string &func, const HNativeRec &rec, const std:
     double *factor = (double *)(base + 2 * map_bytes + planes_bytes + 2 * spec_bytes + partial_bytes);
 
     const float *in_map = nullptr, *filt_map = nullptr;
-    if (native_input_map(who, img, images, w, h, in_tmp, &in_map, s, err) != 0) return -1;
-    if ((is_conv || is_half) && native_input_map(who, rec.args[1].img, images, w, h, filt_tmp, &filt_map, s, err) != 0) return -1;
+    if (native_input_map(who, img, images, ws.env, w, h, in_tmp, &in_map, s, err) != 0) return -1;
+    if ((is_conv || is_half) && native_input_map(who, rec.args[1].img, images, ws.env, w, h, filt_tmp, &filt_map, s, err) != 0) return -1;
     if (ensure_plans(ws, w, h, nch, s, err) != 0) return -1;
     FftApi &api = fft_api();
     hipfftHandle fwd = (hipfftHandle)ws.fft_fwd, inv = (hipfftHandle)ws.fft_inv;

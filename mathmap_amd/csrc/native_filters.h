@@ -11,8 +11,18 @@
 
 namespace mm {
 
+// What render_image's pixel fetch reads from the invocation (builtins.c:120-159: get_orig_val_pixel
+// is hard-wired there -- nearest, never bilinear -- but it still honours the invocation's
+// supersampling flag, edge behaviours and edge colours).
+struct NativeEnv {
+    int supersampling = 0;
+    int edge_x = 0, edge_y = 0;                 // 0 colour, 1 wrap, 2 reflect, 3 rotate
+    uint32_t edge_color_x = 0, edge_color_y = 0;
+};
+
 // Scratch buffers reused across calls (sized for the largest map seen).
 struct NativeWorkspace {
+    NativeEnv env;                              // set by the runtime before every run_native_filter
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     void *reserve(size_t bytes);
@@ -50,9 +60,11 @@ int run_native_filter(const std::string &func, const HNativeRec &rec, const std:
 // native_fft.hip: convolve / half_convolve / visualize_fft (native-filters/convolve.c)
 int fft_native_filter(const std::string &func, const HNativeRec &rec, const std::vector<HImageDesc> &images, int render_w,
                       int render_h, float *out_map, NativeWorkspace &ws, hipStream_t stream, std::string *err);
-int native_input_map(const char *who, const HImage &img, const std::vector<HImageDesc> &images, int w, int h, float *dst,
-                     const float **map, hipStream_t s, std::string *err);
+int native_input_map(const char *who, const HImage &img, const std::vector<HImageDesc> &images, const NativeEnv &env, int w,
+                     int h, float *dst, const float **map, hipStream_t s, std::string *err);
 void fft_release_plans(NativeWorkspace &ws);
+// render_image, drawable branch (builtins.c:303-343): `dst` = float[h][w][4]
+void launch_render_drawable(const HImageDesc &in, const HImage &img, const NativeEnv &env, float *dst, int w, int h, hipStream_t s);
 
 void launch_supersample_combine(const unsigned char *longs, const unsigned char *shorts, unsigned char *out, int w, int h,
                                 int bpp, int out_stride, hipStream_t s);

@@ -77,9 +77,8 @@ void find_iir_constants(IirCoef &c, float std_dev) {
 // fx = ((float)x - bx) / ax, ORIG_VAL with the *nearest* fetch, TUPLE_FROM_COLOR.
 __global__ void __launch_bounds__(256) k_render_drawable(const uint32_t *__restrict__ src, int sw, int sh,
                                                          float scale_x, float scale_y, float middle_x, float middle_y,
-                                                         int resized, float xf, float yf, uint32_t edge_x,
-                                                         uint32_t edge_y, int supersampling, float4 *__restrict__ out,
-                                                         int w, int h) {
+                                                         int resized, float xf, float yf, NativeEnv env,
+                                                         float4 *__restrict__ out, int w, int h) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)w * h) return;
     const int px = (int)(i % w), py = (int)(i / w);
@@ -91,14 +90,33 @@ __global__ void __launch_bounds__(256) k_render_drawable(const uint32_t *__restr
     if (resized) { x *= xf; y *= yf; }
     x = (x + middle_x) * scale_x;
     y = -((y - middle_y) * scale_y);
-    if (!supersampling) { x += 0.5; y += 0.5; }
+    if (!env.supersampling) { x += 0.5; y += 0.5; }     // get_orig_val_pixel, builtins.c:153-157
     // cvttsd2si semantics for NaN / out-of-range (see mm_f2i in mm_device.h): INT_MIN, i.e. outside
     const double fx = floor((double)x), fy = floor((double)y);
-    const int ix = (fx >= -2147483648.0 && fx < 2147483648.0) ? (int)fx : (int)0x80000000;
-    const int iy = (fy >= -2147483648.0 && fy < 2147483648.0) ? (int)fy : (int)0x80000000;
+    int ix = (fx >= -2147483648.0 && fx < 2147483648.0) ? (int)fx : (int)0x80000000;
+    int iy = (fy >= -2147483648.0 && fy < 2147483648.0) ? (int)fy : (int)0x80000000;
+    // apply_edge_behaviour (builtins.c:40-119); INT_MIN negates to itself and INT_MIN % n is C's
+    switch (env.edge_x) {
+        case 1: if (ix < 0) ix = ix % sw + sw; else if (ix >= sw) ix %= sw; break;
+        case 2: if (ix < 0) ix = (int)(0u - (unsigned)ix) % sw; else if (ix >= sw) ix = (sw - 1) - (ix % sw); break;
+        case 3:
+            if (ix < 0) { ix = (int)(0u - (unsigned)ix) % sw; iy = (int)((unsigned)(sh - 1) - (unsigned)iy); }
+            else if (ix >= sw) { ix = (sw - 1) - (ix % sw); iy = (int)((unsigned)(sh - 1) - (unsigned)iy); }
+            break;
+        default: break;
+    }
+    switch (env.edge_y) {
+        case 1: if (iy < 0) iy = iy % sh + sh; else if (iy >= sh) iy %= sh; break;
+        case 2: if (iy < 0) iy = (int)(0u - (unsigned)iy) % sh; else if (iy >= sh) iy = (sh - 1) - (iy % sh); break;
+        case 3:
+            if (iy < 0) { ix = (int)((unsigned)(sw - 1) - (unsigned)ix); iy = (int)(0u - (unsigned)iy) % sh; }
+            else if (iy >= sh) { ix = (int)((unsigned)(sw - 1) - (unsigned)ix); iy = (sh - 1) - (iy % sh); }
+            break;
+        default: break;
+    }
     uint32_t c;
-    if (ix < 0 || ix >= sw) c = edge_x;
-    else if (iy < 0 || iy >= sh) c = edge_y;
+    if (ix < 0 || ix >= sw) c = env.edge_color_x;
+    else if (iy < 0 || iy >= sh) c = env.edge_color_y;
     else c = src[(long)iy * sw + ix];
     float4 t;
     t.x = (c >> 24) / 255.0;
@@ -106,6 +124,13 @@ __global__ void __launch_bounds__(256) k_render_drawable(const uint32_t *__restr
     t.z = ((c >> 8) & 0xff) / 255.0;
     t.w = (c & 0xff) / 255.0;
     out[i] = t;
+}
+
+void render_drawable_impl(const HImageDesc &in, const HImage &img, const NativeEnv &env, float *dst, int w, int h, hipStream_t s) {
+    const long n = (long)w * h;
+    k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y,
+                                                                 in.middle_x, in.middle_y, img.resized, img.xf, img.yf, env,
+                                                                 (float4 *)dst, w, h);
 }
 
 // ---- K3/K4: recursive Gaussian along one axis, output written transposed ---------------------
@@ -782,10 +807,7 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
                 return -1;
             }
         } else {
-            const long n = (long)w * h;
-            k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-                (const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y, in.middle_x, in.middle_y, img.resized, img.xf,
-                img.yf, 0u, 0u, 0, (float4 *)out_map, w, h);
+            render_drawable_impl(in, img, ws.env, out_map, w, h, s);
         }
         return 0;
     };
@@ -805,14 +827,14 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
             float x = ((float)i - bx) / ax;
             if (img.resized) x *= img.xf;
             x = (x + in.middle_x) * in.scale_x;
-            x += 0.5;
+            if (!ws.env.supersampling) x += 0.5;
             identity = (int)floor((double)x) == i;
         }
         for (int i = 0; i < h && identity; ++i) {
             float y = ((float)i - by) / ay2;
             if (img.resized) y *= img.yf;
             y = -((y - in.middle_y) * in.scale_y);
-            y += 0.5;
+            if (!ws.env.supersampling) y += 0.5;
             identity = (int)floor((double)y) == i;
         }
     }
@@ -882,18 +904,19 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
 
 }  // namespace
 
+void launch_render_drawable(const HImageDesc &in, const HImage &img, const NativeEnv &env, float *dst, int w, int h, hipStream_t s) {
+    render_drawable_impl(in, img, env, dst, w, h, s);
+}
+
 // The argument image of a native filter as a float map of w x h pixels: its own data when
 // it already is one of that size, otherwise render_image into `dst` (convolve.c:88-95).
-int native_input_map(const char *who, const HImage &img, const std::vector<HImageDesc> &images, int w, int h, float *dst,
-                     const float **map, hipStream_t s, std::string *err) {
+int native_input_map(const char *who, const HImage &img, const std::vector<HImageDesc> &images, const NativeEnv &env, int w,
+                     int h, float *dst, const float **map, hipStream_t s, std::string *err) {
     if (img.idx < 0 || img.idx >= (int)images.size()) { *err = std::string(who) + ": input is not a bitmap image"; return -1; }
     const HImageDesc &in = images[img.idx];
     if (in.kind == IMG_FLOATMAP && in.w == w && in.h == h) { *map = (const float *)in.data; return 0; }
     if (in.kind != IMG_DRAWABLE) { *err = std::string(who) + ": input image is not bound (or a float map of another size)"; return -1; }
-    const long n = (long)w * h;
-    k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-        (const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y, in.middle_x, in.middle_y, img.resized, img.xf,
-        img.yf, 0u, 0u, 0, (float4 *)dst, w, h);
+    launch_render_drawable(in, img, env, dst, w, h, s);
     *map = dst;
     return 0;
 }
@@ -945,10 +968,7 @@ int run_native_filter(const std::string &func, const HNativeRec &rec, const std:
             return 0;
         }
         if (in.kind != IMG_DRAWABLE) { *err = "render(): input image is not bound"; return -1; }
-        const long n = (long)w * h;
-        k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(
-            (const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y, in.middle_x, in.middle_y, img.resized, img.xf,
-            img.yf, 0u, 0u, 0, (float4 *)out_map, w, h);
+        launch_render_drawable(in, img, ws.env, out_map, w, h, stream);
         return 0;
     }
     if (func == "native_filter_convolve" || func == "native_filter_half_convolve" || func == "native_filter_visualize_fft")

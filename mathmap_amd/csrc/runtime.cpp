@@ -656,6 +656,11 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
             inv->native_seen[k] = rec;
             inv->native_seen_gen[k] = inv->input_generation;
         }
+        inv->ws.env.supersampling = f->kopt.supersampling;
+        inv->ws.env.edge_x = f->kopt.edge_x;
+        inv->ws.env.edge_y = f->kopt.edge_y;
+        inv->ws.env.edge_color_x = inv->edge_color_x;
+        inv->ws.env.edge_color_y = inv->edge_color_y;
         int rc = run_native_filter(f->ks.natives[k].func, rec, inv->images, a.render_width, a.render_height,
                                    (float *)inv->native_maps[k], inv->ws, s, &err, &got_lo, &got_hi, dk);
         if (rc != 0) return fail(err);

@@ -429,10 +429,15 @@ def synthetic_image(width, height, seed=1):
     """Deterministic RGB8 test image: smooth gradients plus hashed texture, so gathers
     see non-trivial data.  Returns uint8 [H, W, 3]."""
     import numpy as np
-    y, x = np.mgrid[0:height, 0:width].astype(np.uint32)
+    x = np.arange(width, dtype=np.uint32)[None, :]
     out = np.empty((height, width, 3), np.uint8)
-    for c in range(3):
-        v = (x * np.uint32(131 + 17 * c) + y * np.uint32(71 + 29 * c) + np.uint32(seed * 977 + c * 17)) ^ ((x * y) >> np.uint32(3))
-        g = (x * np.uint32(255) // np.uint32(max(width - 1, 1)) + y * np.uint32(255) // np.uint32(max(height - 1, 1))) // np.uint32(2)
-        out[:, :, c] = ((v & np.uint32(63)) + (g * np.uint32(3)) // np.uint32(4)).astype(np.uint8)
+    gx = x * np.uint32(255) // np.uint32(max(width - 1, 1))
+    for r0 in range(0, height, 1024):          # row chunks: bounded temporaries at 16384^2
+        y = np.arange(r0, min(r0 + 1024, height), dtype=np.uint32)[:, None]
+        gy = y * np.uint32(255) // np.uint32(max(height - 1, 1))
+        g = ((gx + gy) // np.uint32(2) * np.uint32(3)) // np.uint32(4)
+        xy = (x * y) >> np.uint32(3)
+        for c in range(3):
+            v = (x * np.uint32(131 + 17 * c) + y * np.uint32(71 + 29 * c) + np.uint32(seed * 977 + c * 17)) ^ xy
+            out[r0:r0 + y.shape[0], :, c] = ((v & np.uint32(63)) + g).astype(np.uint8)
     return out

@@ -367,6 +367,43 @@ def build_runtime():
     return objs
 
 
+def runtime_library():
+    """The oracle's C runtime as a shared object of its own (for the entry points that are called
+    without a generated filter: gauss_rows)."""
+    rt = build_runtime()
+    so = os.path.join(BUILD, "libmm_oracle_rt.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in rt):
+        _run(["gcc", "-shared", "-o", so + ".tmp"] + rt + ["-lm"])
+        os.replace(so + ".tmp", so)
+    return C.CDLL(so)
+
+
+def gauss_rows(image, hdev, vdev, rows, threads=1):
+    """Rows `rows` of gaussian_blur(image, hdev, vdev) as the reference computes it for a
+    `stretched image` of the canvas size (render_image + gauss_iir, native-filters/gauss.c), as
+    float32 [len(rows), W, 4] -- for frames too large to blur whole in test time.  The vertical
+    pass still runs over every column (spread over `threads`), only the sampled rows are kept."""
+    lib = runtime_library()
+    a = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w, c = a.shape
+    rows_a = np.ascontiguousarray(rows, dtype=np.int32)
+    out = np.zeros((len(rows_a), w, 4), np.float32)
+    lib.mmo_gauss_rows_vertical.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_void_p]
+    lib.mmo_gauss_rows_horizontal.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+
+    def part(lo, hi):
+        lib.mmo_gauss_rows_vertical(a.ctypes.data, c, w, h, vdev, lo, hi, rows_a.ctypes.data, len(rows_a), out.ctypes.data)
+    n = max(1, int(threads))
+    ths = [threading.Thread(target=part, args=(w * k // n, w * (k + 1) // n)) for k in range(n)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    lib.mmo_gauss_rows_horizontal(out.ctypes.data, w, h, len(rows_a), hdev)
+    return out
+
+
 class CpuFilter:
     """A filter compiled by the oracle's cc-equivalent path."""
 

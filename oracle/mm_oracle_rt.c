@@ -352,6 +352,65 @@ void mmo_gauss_iir(float *map, int width, int height, float hdev, float vdev) {
     free(dest);
 }
 
+/* TEST SUPPORT for frames too large to blur whole in test time (BASELINE config 4: 16384 x 16384, a
+ * 4.3 GB float map): rows `rows[0..nrows)` of mmo_gauss_iir(mmo_render_image(drawable)) -- the same
+ * fetch (mmo_orig_val, nearest) and the same iir_line as above, organised so that the caller can
+ * spread the columns of the vertical pass over threads and nothing but the sampled rows is kept.
+ *   step 1, per column range: vertical pass (gauss.c:155-201) of columns [col_lo, col_hi), all four
+ *           channels; the results of the sampled rows go to vmid[nrows][width][4];
+ *   step 2: horizontal pass (gauss.c:203-252) of those rows, in place.
+ * `img` is a width x height drawable of `channels` bytes per pixel bound to a `stretched image`
+ * argument of a stretched filter (no resize factors), like examples/Blur/Gaussian Blur.mm. */
+void mmo_gauss_rows_vertical(const unsigned char *img, int channels, int width, int height, float vdev_uv, int col_lo,
+                             int col_hi, const int *rows, int nrows, float *vmid) {
+    double n_p[5], n_m[5], d_p[5], d_m[5], bd_p[5], bd_m[5];
+    double *val_p = malloc(height * sizeof(double)), *val_m = malloc(height * sizeof(double));
+    float *src = malloc((size_t)height * 4 * sizeof(float)), *dest = malloc(height * sizeof(float));
+    float *line = malloc(height * sizeof(float));
+    mmo_args B;
+    mmo_image_desc d, fm;
+    mmo_image in;
+    int col, channel, i, k;
+    memset(&B, 0, sizeof B);
+    mmo_fill_drawable_desc(&d, img, width, height, channels);
+    B.images = &d;
+    B.num_images = 1;
+    in.idx = 0; in.pw = width; in.ph = height; in.xf = in.yf = 1.0f; in.resized = 0;
+    mmo_fill_floatmap_desc(&fm, NULL, width, height);
+    mmo_find_iir_constants(n_p, n_m, d_p, d_m, bd_p, bd_m, fabs(vdev_uv * fm.ay));      /* gauss.c:659-660 */
+    for (col = col_lo; col < col_hi; ++col) {
+        float fx = ((float)col - fm.bx) / fm.ax;                                        /* builtins.c:324-333 */
+        for (i = 0; i < height; ++i) {
+            float fy = ((float)i - fm.by) / fm.ay;
+            mmo_tup4 t = mmo_orig_val(&B, fx, fy, in, 0.0);
+            memcpy(src + (size_t)i * 4, t.v, 4 * sizeof(float));
+        }
+        for (channel = 0; channel < 4; ++channel) {
+            for (i = 0; i < height; ++i) line[i] = src[(size_t)i * 4 + channel];
+            iir_line(line, dest, height, n_p, n_m, d_p, d_m, bd_p, bd_m, val_p, val_m);
+            for (k = 0; k < nrows; ++k) vmid[((size_t)k * width + col) * 4 + channel] = dest[rows[k]];
+        }
+    }
+    free(val_p); free(val_m); free(src); free(dest); free(line);
+}
+
+void mmo_gauss_rows_horizontal(float *vmid, int width, int height, int nrows, float hdev_uv) {
+    double n_p[5], n_m[5], d_p[5], d_m[5], bd_p[5], bd_m[5];
+    double *val_p = malloc(width * sizeof(double)), *val_m = malloc(width * sizeof(double));
+    float *src = malloc(width * sizeof(float)), *dest = malloc(width * sizeof(float));
+    mmo_image_desc fm;
+    int k, channel, i;
+    mmo_fill_floatmap_desc(&fm, NULL, width, height);
+    mmo_find_iir_constants(n_p, n_m, d_p, d_m, bd_p, bd_m, fabs(hdev_uv * fm.ax));
+    for (channel = 0; channel < 4; ++channel)
+        for (k = 0; k < nrows; ++k) {
+            for (i = 0; i < width; ++i) src[i] = vmid[((size_t)k * width + i) * 4 + channel];
+            iir_line(src, dest, width, n_p, n_m, d_p, d_m, bd_p, bd_m, val_p, val_m);
+            for (i = 0; i < width; ++i) vmid[((size_t)k * width + i) * 4 + channel] = dest[i];
+        }
+    free(val_p); free(val_m); free(src); free(dest);
+}
+
 /* native_filter_gaussian_blur, gauss.c:641-670, with the per-invocation memo of
  * native-filters/cache.c:110-156 (keyed by input image and the two float args). */
 mmo_image mmo_native_gaussian_blur(const mmo_args *A, int slot, mmo_image in, float hdev, float vdev) {

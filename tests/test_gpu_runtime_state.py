@@ -86,3 +86,31 @@ def test_replacing_an_input_image_releases_the_old_upload():
     assert np.array_equal(got, first) and stats(got, want)[0] <= 1
     inv.set_image("in", b)
     assert stats(inv.render(t=0.1), cf.render(w, h, images={"in": b}, t=0.1))[0] <= 1
+
+
+EDGE_BLUR = """
+filter eb (image in, float s: 0-1 (0.03))
+  b = gaussian_blur(in, s, s);
+  b(xy * 0.9)
+end
+"""
+
+
+@pytest.mark.parametrize("intersample", [False, True])
+@pytest.mark.parametrize("supersampling", [False, True])
+@pytest.mark.parametrize("ex,ey", [(0, 0), (1, 2), (3, 3), (2, 1)])
+def test_native_filter_input_honours_edges_and_supersampling(ex, ey, supersampling, intersample):
+    """render_image's fetch is get_orig_val_pixel (builtins.c:306): always nearest, but with the
+    invocation's supersampling flag (no +0.5), edge behaviours and edge colours.  A non-square input
+    smaller than the canvas, so the blur's input map samples outside the image."""
+    w, h = 160, 96
+    img = W.synthetic_image(53, 37, seed=21)
+    colors = (0x20406080, 0xC0A01055)
+    flt = mm.Filter(EDGE_BLUR, intersample=intersample, supersampling=supersampling, edge_x=ex, edge_y=ey)
+    inv = flt.invoke(w, h)
+    inv.set_image("in", img)
+    inv.set_edge_colors(*colors)
+    got = inv.render()
+    want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, intersample=intersample, supersampling=supersampling,
+                                             edge=(ex, ey), edge_colors=colors)
+    assert np.array_equal(got, want), stats(got, want)
