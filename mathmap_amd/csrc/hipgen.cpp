@@ -913,6 +913,11 @@ struct Generator {
                "#define MMF_SIN_SLOW(a) sin((a))\n#define MMF_COS_SLOW(a) cos((a))\n"
                "#define MMF_LDEXP(a, e) __builtin_ldexp((a), (e))\n#define MMF_EXP_SLOW(a) exp((a))\n#define MMF_LOG_SLOW(a) log((a))\n"
                "#define MMF_POW_SLOW(a, b) pow((a), (b))\n"
+               // mm_glibcf.h (glibc's float algorithms for the complex ops); float sqrt / division are the correctly
+               // rounded device ones, double sqrt is the compiler's correctly rounded expansion
+               "#define MMQ_FN static __device__ __forceinline__\n#define MMQ_TABLE static __device__ const\n"
+               "#define MMQ_FMA(a, b, c) __builtin_fma((a), (b), (c))\n#define MMQ_SQRT(a) sqrt((a))\n"
+               "#define MMQ_SQRTF(a) sqrtf((a))\n"
             << device_fastmath_prelude() << "\n";
         out << device_prelude() << "\n";
         if (uses_noise(code.body)) {

@@ -257,8 +257,9 @@ MM_DEV mm_pf mm_sqrt2(mm_pf a) { return mm_pf{mm_sqrt_f32(a.x), mm_sqrt_f32(a.y)
 
 // ---- complex (float _Complex) -----------------------------------------------------------
 // In the generated C, complex values only flow COMPLEX() -> c*f() -> crealf/cimagf
-// (builtins.lisp:679-941).  The functions below compute in double and round once;
-// glibc's float versions are within 1 ulp of the same values.
+// (builtins.lisp:679-941).  csqrtf cexpf clogf cpowf cargf and the six trigonometric / hyperbolic
+// functions run glibc's own float algorithms (mm_glibcf.h); the inverse functions and cgamma still
+// compute in double and round once (<= 1-2 float ulps from glibc's).
 MM_DEV mm_complex mm_cmake(float r, float i) { mm_complex c; c.re = r; c.im = i; return c; }
 #define COMPLEX(r, i) mm_cmake((float)(r), (float)(i))
 MM_DEV float crealf(mm_complex c) { return c.re; }
@@ -293,55 +294,22 @@ MM_DEV mm_dc mm_dcsqrt(mm_dc z) {
     return mm_dcmake(fabs(z.im) / (2.0 * t), copysign(t, z.im));
 }
 
-MM_DEV mm_complex csqrtf(mm_complex z) { return mm_narrow(mm_dcsqrt(mm_widen(z))); }
-MM_DEV mm_complex cexpf(mm_complex z) { return mm_narrow(mm_dcexp(mm_widen(z))); }
-MM_DEV mm_complex clogf(mm_complex z) {   // z widened from floats: the cheap hypot applies
-    const mm_dc w = mm_widen(z);
-    return mm_narrow(mm_dcmake(mmf_log_any(mm_hypot_ff(w.re, w.im)), atan2(w.im, w.re)));
-}
-MM_DEV float cargf(mm_complex z) { return (float)atan2((double)z.im, (double)z.re); }
-// glibc: cpowf(x, c) = cexpf(c * clogf(x)) with every step rounded to float
-MM_DEV mm_complex cpowf(mm_complex x, mm_complex c) {
-    mm_complex l = clogf(x);
-    mm_complex p = mm_cmake(c.re * l.re - c.im * l.im, c.re * l.im + c.im * l.re);
-    return cexpf(p);
-}
-MM_DEV mm_complex csinf(mm_complex z) {
-    double s, c;
-    mmf_sincos_d((double)z.re, &s, &c);
-    return mm_cmake((float)(s * cosh((double)z.im)), (float)(c * sinh((double)z.im)));
-}
-MM_DEV mm_complex ccosf(mm_complex z) {
-    double s, c;
-    mmf_sincos_d((double)z.re, &s, &c);
-    return mm_cmake((float)(c * cosh((double)z.im)), (float)(-s * sinh((double)z.im)));
-}
-MM_DEV mm_complex ctanf(mm_complex z) {
-    double s2, c2;
-    mmf_sincos_d(2.0 * (double)z.re, &s2, &c2);
-    double y2 = 2.0 * (double)z.im;
-    if (fabs(y2) > 700.0) return mm_cmake((float)(4.0 * s2 * exp(-2.0 * fabs(y2)) ), (float)copysign(1.0, y2));
-    double d = c2 + cosh(y2);
-    return mm_cmake((float)(s2 / d), (float)(sinh(y2) / d));
-}
-MM_DEV mm_complex csinhf(mm_complex z) {
-    double s, c;
-    mmf_sincos_d((double)z.im, &s, &c);
-    return mm_cmake((float)(sinh((double)z.re) * c), (float)(cosh((double)z.re) * s));
-}
-MM_DEV mm_complex ccoshf(mm_complex z) {
-    double s, c;
-    mmf_sincos_d((double)z.im, &s, &c);
-    return mm_cmake((float)(cosh((double)z.re) * c), (float)(sinh((double)z.re) * s));
-}
-MM_DEV mm_complex ctanhf(mm_complex z) {
-    double s2, c2;
-    mmf_sincos_d(2.0 * (double)z.im, &s2, &c2);
-    double x2 = 2.0 * (double)z.re;
-    if (fabs(x2) > 700.0) return mm_cmake((float)copysign(1.0, x2), (float)(4.0 * s2 * exp(-2.0 * fabs(x2))));
-    double d = cosh(x2) + c2;
-    return mm_cmake((float)(sinh(x2) / d), (float)(s2 / d));
-}
+// glibc's float algorithms (mm_glibcf.h, verified bit for bit against the host's libm): the reference's
+// generated C calls exactly these (ops.lisp:194-213), and they differ from the correctly rounded value by
+// 1-2 float ulps often enough to show in a frame.
+MM_DEV mm_complex mm_from_q(mmq_cf c) { return mm_cmake(c.re, c.im); }
+MM_DEV mmq_cf mm_to_q(mm_complex c) { return mmq_cmake(c.re, c.im); }
+MM_DEV mm_complex csqrtf(mm_complex z) { return mm_from_q(mmq_csqrtf(mm_to_q(z))); }
+MM_DEV mm_complex cexpf(mm_complex z) { return mm_from_q(mmq_cexpf(mm_to_q(z))); }
+MM_DEV mm_complex clogf(mm_complex z) { return mm_from_q(mmq_clogf(mm_to_q(z))); }
+MM_DEV float cargf(mm_complex z) { return mmq_cargf(mm_to_q(z)); }
+MM_DEV mm_complex cpowf(mm_complex x, mm_complex c) { return mm_from_q(mmq_cpowf(mm_to_q(x), mm_to_q(c))); }
+MM_DEV mm_complex csinf(mm_complex z) { return mm_from_q(mmq_csinf(mm_to_q(z))); }
+MM_DEV mm_complex ccosf(mm_complex z) { return mm_from_q(mmq_ccosf(mm_to_q(z))); }
+MM_DEV mm_complex ctanf(mm_complex z) { return mm_from_q(mmq_ctanf(mm_to_q(z))); }
+MM_DEV mm_complex csinhf(mm_complex z) { return mm_from_q(mmq_csinhf(mm_to_q(z))); }
+MM_DEV mm_complex ccoshf(mm_complex z) { return mm_from_q(mmq_ccoshf(mm_to_q(z))); }
+MM_DEV mm_complex ctanhf(mm_complex z) { return mm_from_q(mmq_ctanhf(mm_to_q(z))); }
 MM_DEV mm_dc mm_dcasinh(mm_dc z) {
     mm_dc one = mm_dcmake(1.0, 0.0);
     // fold into the right half plane for accuracy, asinh is odd

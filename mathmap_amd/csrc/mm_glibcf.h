@@ -53,6 +53,7 @@ MMQ_FN float mmq_copysignf(float x, float s) { return mmq_asfloat((mmq_asuint(x)
 MMQ_FN int mmq_isnanf(float x) { return (mmq_asuint(x) & 0x7fffffffu) > 0x7f800000u; }
 MMQ_FN int mmq_isinff(float x) { return (mmq_asuint(x) & 0x7fffffffu) == 0x7f800000u; }
 MMQ_FN int mmq_isfinitef(float x) { return (mmq_asuint(x) & 0x7fffffffu) < 0x7f800000u; }
+MMQ_FN int mmq_issignalingf(float x) { return mmq_isnanf(x) && !(mmq_asuint(x) & 0x00400000u); }
 MMQ_FN int mmq_signbitf(float x) { return (int)(mmq_asuint(x) >> 31); }
 MMQ_FN float mmq_nanf(void) { return mmq_asfloat(0x7fc00000u); }
 MMQ_FN float mmq_inff(void) { return mmq_asfloat(0x7f800000u); }
@@ -283,7 +284,7 @@ MMQ_FN float mmq_atan2f(float y, float x) {
 // ---- hypotf (e_hypotf.c, 2.35), x2y2m1f, scalbnf ---------------------------------------------
 MMQ_FN float mmq_hypotf(float x, float y) {
     if (!mmq_isfinitef(x) || !mmq_isfinitef(y)) {
-        if (mmq_isinff(x) || mmq_isinff(y)) return mmq_inff();      /* (signalling NaNs aside) */
+        if ((mmq_isinff(x) || mmq_isinff(y)) && !mmq_issignalingf(x) && !mmq_issignalingf(y)) return mmq_inff();
         return x + y;
     }
     return (float)MMQ_SQRT((double)x * (double)x + (double)y * (double)y);
@@ -498,5 +499,431 @@ MMQ_FN mmq_cf mmq_cmulf(mmq_cf p, mmq_cf q) {
 }
 
 MMQ_FN mmq_cf mmq_cpowf(mmq_cf x, mmq_cf c) { return mmq_cexpf(mmq_cmulf(c, mmq_clogf(x))); }
+
+// ---- expm1f (s_expm1f.c), sinhf (e_sinhf.c), coshf (e_coshf.c) ------------------------------------------
+#define MMQ_HAVE_BATCH2 1
+MMQ_FN float mmq_expm1f(float x) {
+    const float huge = 1.0e+30f, tiny = 1.0e-30f, o_threshold = 8.8721679688e+01f, ln2_hi = 6.9313812256e-01f,
+                ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f, Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f,
+                Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+    float y, hi, lo, c = 0.0f, t, e, hxs, hfx, r1;
+    int k;
+    unsigned hx = mmq_asuint(x);
+    const unsigned xsb = hx & 0x80000000u;
+    hx &= 0x7fffffffu;
+    if (hx >= 0x4195b844u) {                      /* |x| >= 27 ln2 */
+        if (hx >= 0x42b17218u) {                  /* |x| >= 88.721... */
+            if (hx > 0x7f800000u) return x + x;
+            if (hx == 0x7f800000u) return xsb == 0 ? x : -1.0f;
+            if (x > o_threshold) return huge * huge;
+        }
+        if (xsb != 0) return tiny - 1.0f;         /* x < -27 ln2 */
+    }
+    if (hx > 0x3eb17218u) {                       /* |x| > 0.5 ln2 */
+        if (hx < 0x3F851592u) {                   /* and |x| < 1.5 ln2 */
+            if (xsb == 0) { hi = x - ln2_hi; lo = ln2_lo; k = 1; }
+            else { hi = x + ln2_hi; lo = -ln2_lo; k = -1; }
+        } else {
+            k = (int)(invln2 * x + (xsb == 0 ? 0.5f : -0.5f));
+            t = (float)k;
+            hi = x - t * ln2_hi;
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (hx < 0x33000000u) {                /* |x| < 2^-25 */
+        t = huge + x;
+        return x - (t - (huge + x));
+    } else
+        k = 0;
+    hfx = 0.5f * x;
+    hxs = x * hfx;
+    r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    t = 3.0f - r1 * hfx;
+    e = hxs * ((r1 - t) / (6.0f - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = (x * (e - c) - c);
+    e -= hxs;
+    if (k == -1) return 0.5f * (x - e) - 0.5f;
+    if (k == 1) {
+        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+        return 1.0f + 2.0f * (x - e);
+    }
+    if (k <= -2 || k > 56) {                      /* suffice to return exp(x) - 1 */
+        y = 1.0f - (e - x);
+        y = mmq_asfloat(mmq_asuint(y) + ((unsigned)k << 23));
+        return y - 1.0f;
+    }
+    if (k < 23) {
+        t = mmq_asfloat(0x3f800000u - (0x1000000u >> k));      /* 1 - 2^-k */
+        y = t - (e - x);
+        y = mmq_asfloat(mmq_asuint(y) + ((unsigned)k << 23));
+    } else {
+        t = mmq_asfloat((unsigned)(0x7f - k) << 23);           /* 2^-k */
+        y = x - (e + t);
+        y += 1.0f;
+        y = mmq_asfloat(mmq_asuint(y) + ((unsigned)k << 23));
+    }
+    return y;
+}
+
+MMQ_FN float mmq_sinhf(float x) {
+    const float shuge = 1.0e37f;
+    float t, w, h;
+    const int jx = (int)mmq_asuint(x), ix = jx & 0x7fffffff;
+    if (ix >= 0x7f800000) return x + x;
+    h = 0.5f;
+    if (jx < 0) h = -h;
+    if (ix < 0x41b00000) {                        /* |x| < 22 */
+        if (ix < 0x31800000) return x;            /* |x| < 2^-28 */
+        t = mmq_expm1f(mmq_fabsf(x));
+        if (ix < 0x3f800000) return h * (2.0f * t - t * t / (t + 1.0f));
+        return h * (t + t / (t + 1.0f));
+    }
+    if (ix <= 0x42b1717f) return h * mmq_expf(mmq_fabsf(x));      /* |x| < 88.7216796875 (the binary's bound) */
+    if (ix <= 0x42b2d4fc) {
+        w = mmq_expf(0.5f * mmq_fabsf(x));
+        t = h * w;
+        return t * w;
+    }
+    return x * shuge;
+}
+
+MMQ_FN float mmq_coshf(float x) {
+    const float huge = 1.0e30f;
+    float t, w;
+    const int ix = (int)(mmq_asuint(x) & 0x7fffffffu);
+    if (ix < 0x41b00000) {                        /* |x| < 22 */
+        if (ix < 0x3eb17218) {                    /* |x| < 0.5 ln2 */
+            if (ix < 0x24000000) return 1.0f;
+            t = mmq_expm1f(mmq_fabsf(x));
+            w = 1.0f + t;
+            return 1.0f + (t * t) / (w + w);
+        }
+        t = mmq_expf(mmq_fabsf(x));
+        return 0.5f * t + 0.5f / t;
+    }
+    if (ix <= 0x42b1717f) return 0.5f * mmq_expf(mmq_fabsf(x));
+    if (ix <= 0x42b2d4fc) {
+        w = mmq_expf(0.5f * mmq_fabsf(x));
+        t = 0.5f * w;
+        return t * w;
+    }
+    if (ix >= 0x7f800000) return x * x;
+    return huge * huge;
+}
+
+// ---- csqrtf, csinhf, ccoshf, csinf, ccosf, ctanhf, ctanf (math/s_c*_template.c) ---------------------------
+MMQ_FN mmq_cf mmq_csqrtf(mmq_cf x) {
+    mmq_cf res;
+    const int rnan = mmq_isnanf(x.re), inan = mmq_isnanf(x.im), rinf = mmq_isinff(x.re), iinf = mmq_isinff(x.im);
+    if (rnan || inan || rinf || iinf) {
+        if (iinf) { res.re = mmq_inff(); res.im = x.im; }
+        else if (rinf) {
+            if (x.re < 0.0f) { res.re = inan ? mmq_nanf() : 0.0f; res.im = mmq_copysignf(mmq_inff(), x.im); }
+            else { res.re = x.re; res.im = inan ? mmq_nanf() : mmq_copysignf(0.0f, x.im); }
+        } else { res.re = mmq_nanf(); res.im = mmq_nanf(); }
+        return res;
+    }
+    if (x.im == 0.0f) {
+        if (x.re < 0.0f) { res.re = 0.0f; res.im = mmq_copysignf(MMQ_SQRTF(-x.re), x.im); }
+        else { res.re = mmq_fabsf(MMQ_SQRTF(x.re)); res.im = mmq_copysignf(0.0f, x.im); }
+        return res;
+    }
+    if (x.re == 0.0f) {
+        float r;
+        if (mmq_fabsf(x.im) >= 2.0f * MMQ_FLT_MIN) r = MMQ_SQRTF(0.5f * mmq_fabsf(x.im));
+        else r = 0.5f * MMQ_SQRTF(2.0f * mmq_fabsf(x.im));
+        res.re = r;
+        res.im = mmq_copysignf(r, x.im);
+        return res;
+    }
+    float d, r, s;
+    int scale = 0;
+    if (mmq_fabsf(x.re) > MMQ_FLT_MAX / 4.0f) {
+        scale = 1;
+        x.re = mmq_scalbnf(x.re, -2);
+        x.im = mmq_scalbnf(x.im, -2);
+    } else if (mmq_fabsf(x.im) > MMQ_FLT_MAX / 4.0f) {
+        scale = 1;
+        if (mmq_fabsf(x.re) >= 4.0f * MMQ_FLT_MIN) x.re = mmq_scalbnf(x.re, -2);
+        else x.re = 0.0f;
+        x.im = mmq_scalbnf(x.im, -2);
+    } else if (mmq_fabsf(x.re) < 2.0f * MMQ_FLT_MIN && mmq_fabsf(x.im) < 2.0f * MMQ_FLT_MIN) {
+        scale = -((24 + 1) / 2);
+        x.re = mmq_scalbnf(x.re, -2 * scale);
+        x.im = mmq_scalbnf(x.im, -2 * scale);
+    }
+    d = mmq_hypotf(x.re, x.im);
+    if (x.re > 0.0f) {
+        r = MMQ_SQRTF(0.5f * (d + x.re));
+        if (scale == 1 && mmq_fabsf(x.im) < 1.0f) {
+            s = x.im / r;
+            r = mmq_scalbnf(r, scale);
+            scale = 0;
+        } else
+            s = 0.5f * (x.im / r);
+    } else {
+        s = MMQ_SQRTF(0.5f * (d - x.re));
+        if (scale == 1 && mmq_fabsf(x.im) < 1.0f) {
+            r = mmq_fabsf(x.im / s);
+            s = mmq_scalbnf(s, scale);
+            scale = 0;
+        } else
+            r = mmq_fabsf(0.5f * (x.im / s));
+    }
+    if (scale) {
+        r = mmq_scalbnf(r, scale);
+        s = mmq_scalbnf(s, scale);
+    }
+    res.re = r;
+    res.im = mmq_copysignf(s, x.im);
+    return res;
+}
+
+MMQ_FN void mmq_sincos_or_tiny(float v, float *s, float *c) {
+    if (mmq_fabsf(v) > MMQ_FLT_MIN) { const mmq_sc sc = mmq_sincosf(v); *s = sc.s; *c = sc.c; }
+    else { *s = v; *c = 1.0f; }
+}
+
+MMQ_FN mmq_cf mmq_csinhf(mmq_cf x) {
+    mmq_cf r;
+    const int negate = mmq_signbitf(x.re);
+    const int rfin = mmq_isfinitef(x.re), ifin = mmq_isfinitef(x.im);
+    x.re = mmq_fabsf(x.re);
+    if (rfin) {
+        if (ifin) {
+            const int t = 88;
+            float sinix, cosix;
+            mmq_sincos_or_tiny(x.im, &sinix, &cosix);
+            if (negate) cosix = -cosix;
+            if (mmq_fabsf(x.re) > t) {
+                const float exp_t = mmq_expf((float)t);
+                float rx = mmq_fabsf(x.re);
+                rx -= t;
+                sinix *= exp_t / 2.0f;
+                cosix *= exp_t / 2.0f;
+                if (rx > t) { rx -= t; sinix *= exp_t; cosix *= exp_t; }
+                if (rx > t) { r.re = MMQ_FLT_MAX * cosix; r.im = MMQ_FLT_MAX * sinix; }
+                else { const float ev = mmq_expf(rx); r.re = ev * cosix; r.im = ev * sinix; }
+            } else {
+                r.re = mmq_sinhf(x.re) * cosix;
+                r.im = mmq_coshf(x.re) * sinix;
+            }
+            return r;
+        }
+        if (x.re == 0.0f) { r.re = mmq_copysignf(0.0f, negate ? -1.0f : 1.0f); r.im = x.im - x.im; }
+        else { r.re = mmq_nanf(); r.im = mmq_nanf(); }
+        return r;
+    }
+    if (mmq_isinff(x.re)) {
+        if (ifin && x.im != 0.0f) {
+            float sinix, cosix;
+            mmq_sincos_or_tiny(x.im, &sinix, &cosix);
+            r.re = mmq_copysignf(mmq_inff(), cosix);
+            r.im = mmq_copysignf(mmq_inff(), sinix);
+            if (negate) r.re = -r.re;
+        } else if (x.im == 0.0f) {
+            r.re = negate ? -mmq_inff() : mmq_inff();
+            r.im = x.im;
+        } else {
+            r.re = mmq_inff();
+            r.im = x.im - x.im;
+        }
+        return r;
+    }
+    r.re = mmq_nanf();
+    r.im = x.im == 0.0f ? x.im : mmq_nanf();
+    return r;
+}
+
+MMQ_FN mmq_cf mmq_ccoshf(mmq_cf x) {
+    mmq_cf r;
+    const int rfin = mmq_isfinitef(x.re), ifin = mmq_isfinitef(x.im);
+    if (rfin) {
+        if (ifin) {
+            const int t = 88;
+            float sinix, cosix;
+            mmq_sincos_or_tiny(x.im, &sinix, &cosix);
+            if (mmq_fabsf(x.re) > t) {
+                const float exp_t = mmq_expf((float)t);
+                float rx = mmq_fabsf(x.re);
+                if (mmq_signbitf(x.re)) sinix = -sinix;
+                rx -= t;
+                sinix *= exp_t / 2.0f;
+                cosix *= exp_t / 2.0f;
+                if (rx > t) { rx -= t; sinix *= exp_t; cosix *= exp_t; }
+                if (rx > t) { r.re = MMQ_FLT_MAX * cosix; r.im = MMQ_FLT_MAX * sinix; }
+                else { const float ev = mmq_expf(rx); r.re = ev * cosix; r.im = ev * sinix; }
+            } else {
+                r.re = mmq_coshf(x.re) * cosix;
+                r.im = mmq_sinhf(x.re) * sinix;
+            }
+            return r;
+        }
+        r.im = x.re == 0.0f ? 0.0f : mmq_nanf();
+        r.re = x.im - x.im;
+        return r;
+    }
+    if (mmq_isinff(x.re)) {
+        if (ifin && x.im != 0.0f) {
+            float sinix, cosix;
+            mmq_sincos_or_tiny(x.im, &sinix, &cosix);
+            r.re = mmq_copysignf(mmq_inff(), cosix);
+            r.im = mmq_copysignf(mmq_inff(), sinix) * mmq_copysignf(1.0f, x.re);
+        } else if (x.im == 0.0f) {
+            r.re = mmq_inff();
+            r.im = x.im * mmq_copysignf(1.0f, x.re);
+        } else {
+            r.re = mmq_inff();
+            r.im = x.im - x.im;
+        }
+        return r;
+    }
+    r.re = mmq_nanf();
+    r.im = x.im == 0.0f ? x.im : mmq_nanf();
+    return r;
+}
+
+MMQ_FN mmq_cf mmq_csinf(mmq_cf x) {
+    mmq_cf r;
+    const int negate = mmq_signbitf(x.re);
+    const int rfin = mmq_isfinitef(x.re), ifin = mmq_isfinitef(x.im);
+    x.re = mmq_fabsf(x.re);
+    if (ifin) {
+        if (rfin) {
+            const int t = 88;
+            float sinix, cosix;
+            if (x.re > MMQ_FLT_MIN) { const mmq_sc sc = mmq_sincosf(x.re); sinix = sc.s; cosix = sc.c; }
+            else { sinix = x.re; cosix = 1.0f; }
+            if (negate) sinix = -sinix;
+            if (mmq_fabsf(x.im) > t) {
+                const float exp_t = mmq_expf((float)t);
+                float ix = mmq_fabsf(x.im);
+                if (mmq_signbitf(x.im)) cosix = -cosix;
+                ix -= t;
+                sinix *= exp_t / 2.0f;
+                cosix *= exp_t / 2.0f;
+                if (ix > t) { ix -= t; sinix *= exp_t; cosix *= exp_t; }
+                if (ix > t) { r.re = MMQ_FLT_MAX * sinix; r.im = MMQ_FLT_MAX * cosix; }
+                else { const float ev = mmq_expf(ix); r.re = ev * sinix; r.im = ev * cosix; }
+            } else {
+                r.re = mmq_coshf(x.im) * sinix;
+                r.im = mmq_sinhf(x.im) * cosix;
+            }
+            return r;
+        }
+        if (x.im == 0.0f) { r.re = x.re - x.re; r.im = x.im; }
+        else { r.re = mmq_nanf(); r.im = mmq_nanf(); }
+        return r;
+    }
+    if (mmq_isinff(x.im)) {
+        if (x.re == 0.0f) {
+            r.re = mmq_copysignf(0.0f, negate ? -1.0f : 1.0f);
+            r.im = x.im;
+        } else if (rfin) {
+            float sinix, cosix;
+            if (x.re > MMQ_FLT_MIN) { const mmq_sc sc = mmq_sincosf(x.re); sinix = sc.s; cosix = sc.c; }
+            else { sinix = x.re; cosix = 1.0f; }
+            r.re = mmq_copysignf(mmq_inff(), sinix);
+            r.im = mmq_copysignf(mmq_inff(), cosix);
+            if (negate) r.re = -r.re;
+            if (mmq_signbitf(x.im)) r.im = -r.im;
+        } else {
+            r.re = x.re - x.re;
+            r.im = mmq_inff();
+        }
+        return r;
+    }
+    r.re = (x.re == 0.0f) ? mmq_copysignf(0.0f, negate ? -1.0f : 1.0f) : mmq_nanf();
+    r.im = mmq_nanf();
+    return r;
+}
+
+MMQ_FN mmq_cf mmq_ccosf(mmq_cf x) { return mmq_ccoshf(mmq_cmake(-x.im, x.re)); }
+
+MMQ_FN mmq_cf mmq_ctanhf(mmq_cf x) {
+    mmq_cf res;
+    if (!mmq_isfinitef(x.re) || !mmq_isfinitef(x.im)) {
+        if (mmq_isinff(x.re)) {
+            res.re = mmq_copysignf(1.0f, x.re);
+            if (mmq_isfinitef(x.im) && mmq_fabsf(x.im) > 1.0f) {
+                const mmq_sc sc = mmq_sincosf(x.im);
+                res.im = mmq_copysignf(0.0f, sc.s * sc.c);
+            } else
+                res.im = mmq_copysignf(0.0f, x.im);
+        } else if (x.im == 0.0f) {
+            res = x;
+        } else {
+            res.re = (x.re == 0.0f) ? x.re : mmq_nanf();
+            res.im = mmq_nanf();
+        }
+        return res;
+    }
+    float sinix, cosix, den;
+    const int t = 44;                       /* (int)((FLT_MAX_EXP - 1) * M_LN2 / 2) */
+    mmq_sincos_or_tiny(x.im, &sinix, &cosix);
+    if (mmq_fabsf(x.re) > t) {
+        const float exp_2t = mmq_expf((float)(2 * t));
+        res.re = mmq_copysignf(1.0f, x.re);
+        res.im = 4.0f * sinix * cosix;
+        x.re = mmq_fabsf(x.re);
+        x.re -= t;
+        res.im /= exp_2t;
+        if (x.re > t) res.im /= exp_2t;
+        else res.im /= mmq_expf(2.0f * x.re);
+    } else {
+        float sinhrx, coshrx;
+        if (mmq_fabsf(x.re) > MMQ_FLT_MIN) { sinhrx = mmq_sinhf(x.re); coshrx = mmq_coshf(x.re); }
+        else { sinhrx = x.re; coshrx = 1.0f; }
+        if (mmq_fabsf(sinhrx) > mmq_fabsf(cosix) * MMQ_FLT_EPSILON) den = sinhrx * sinhrx + cosix * cosix;
+        else den = cosix * cosix;
+        res.re = sinhrx * coshrx / den;
+        res.im = sinix * cosix / den;
+    }
+    return res;
+}
+
+MMQ_FN mmq_cf mmq_ctanf(mmq_cf x) {
+    mmq_cf res;
+    if (!mmq_isfinitef(x.re) || !mmq_isfinitef(x.im)) {
+        if (mmq_isinff(x.im)) {
+            if (mmq_isfinitef(x.re) && mmq_fabsf(x.re) > 1.0f) {
+                const mmq_sc sc = mmq_sincosf(x.re);
+                res.re = mmq_copysignf(0.0f, sc.s * sc.c);
+            } else
+                res.re = mmq_copysignf(0.0f, x.re);
+            res.im = mmq_copysignf(1.0f, x.im);
+        } else if (x.re == 0.0f) {
+            res = x;
+        } else {
+            res.re = mmq_nanf();
+            res.im = (x.im == 0.0f) ? x.im : mmq_nanf();
+        }
+        return res;
+    }
+    float sinrx, cosrx, den;
+    const int t = 44;
+    mmq_sincos_or_tiny(x.re, &sinrx, &cosrx);
+    if (mmq_fabsf(x.im) > t) {
+        const float exp_2t = mmq_expf((float)(2 * t));
+        res.im = mmq_copysignf(1.0f, x.im);
+        res.re = 4.0f * sinrx * cosrx;
+        x.im = mmq_fabsf(x.im);
+        x.im -= t;
+        res.re /= exp_2t;
+        if (x.im > t) res.re /= exp_2t;
+        else res.re /= mmq_expf(2.0f * x.im);
+    } else {
+        float sinhix, coshix;
+        if (mmq_fabsf(x.im) > MMQ_FLT_MIN) { sinhix = mmq_sinhf(x.im); coshix = mmq_coshf(x.im); }
+        else { sinhix = x.im; coshix = 1.0f; }
+        if (mmq_fabsf(sinhix) > mmq_fabsf(cosrx) * MMQ_FLT_EPSILON) den = cosrx * cosrx + sinhix * sinhix;
+        else den = cosrx * cosrx;
+        res.re = sinrx * cosrx / den;
+        res.im = sinhix * coshix / den;
+    }
+    return res;
+}
 
 #endif  /* MM_GLIBCF_H */
