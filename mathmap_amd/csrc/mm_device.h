@@ -261,7 +261,11 @@ MM_DEV mm_pf mm_sqrt2(mm_pf a) { return mm_pf{mm_sqrt_f32(a.x), mm_sqrt_f32(a.y)
 // functions run glibc's own float algorithms (mm_glibcf.h); the inverse functions and cgamma still
 // compute in double and round once (<= 1-2 float ulps from glibc's).
 MM_DEV mm_complex mm_cmake(float r, float i) { mm_complex c; c.re = r; c.im = i; return c; }
-#define COMPLEX(r, i) mm_cmake((float)(r), (float)(i))
+// opmacros.h:63: COMPLEX(r, i) = (r) + (i) * I.  C's I is the complex value (0, 1), so gcc evaluates the real part
+// as r + i * 0.0f: NaN for an infinite or NaN imaginary part, and -0 + (+0) = +0 for r = -0 with i >= +0 -- both
+// visible behind the branch cuts of clogf / csqrtf.  Same two float operations here.
+MM_DEV mm_complex mm_complex_from_parts(float r, float i) { return mm_cmake(r + i * 0.0f, i); }
+#define COMPLEX(r, i) mm_complex_from_parts((float)(r), (float)(i))
 MM_DEV float crealf(mm_complex c) { return c.re; }
 MM_DEV float cimagf(mm_complex c) { return c.im; }
 

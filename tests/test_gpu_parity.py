@@ -1041,3 +1041,32 @@ def test_reference_suite_on_gpu(case, marlene):
     want = load_png_rgb(case["golden"])
     mx, nd, n1 = stats(got[:, :, :3], want)
     EXP_GOLDEN.check(case["golden"], mx, nd, n1, want.size)
+
+
+SPECIAL_SCALARS = [0.0, -0.0, 1.0, -1.0, 0.5, 2.5, -3.75, 1e-40, -1e-40, 1e-30, 88.5, -104.0, 200.0, 3e38, -3e38,
+                   float("inf"), float("-inf"), float("nan")]
+COMPLEX_SPECIAL_FUNCS = ["exp(z)", "log(z)", "sqrt(z)", "sin(z)", "cos(z)", "tan(z)", "z^ri:[1.3,0.4]", "ri:[0.3,-0.8]^z",
+                         "sinh(z)", "cosh(z)", "tanh(z)"]
+
+
+@pytest.mark.parametrize("expr", COMPLEX_SPECIAL_FUNCS)
+def test_complex_math_special_values(expr):
+    """Zeros of both signs, subnormals, overflow thresholds, infinities and NaN in either component (the
+    values arrive as user values, so nothing folds at compile time): the device's restated glibc
+    functions must take the same special-case branches as glibc -- same finite bits, same infinities
+    and zeros with the same signs, NaN where glibc returns NaN."""
+    import itertools
+    src = "filter probe (float a: -1-1 (0), float b: -1-1 (0)) z = ri:[a, b]; w = %s; rgba:[w[0], w[1], w[0], w[1]] end" % expr
+    flt = mm.Filter(src)
+    cf = CpuFilter(flt.ir_json_raw)
+    inv = flt.invoke(2, 2)
+    bad = []
+    for a, b in itertools.product(SPECIAL_SCALARS, SPECIAL_SCALARS):
+        inv.set("a", a)
+        inv.set("b", b)
+        got = render_device(inv, 2, 2, floatmap=True)[0, 0, :2]
+        want = cf.render(2, 2, uservals={"a": a, "b": b}, floatmap=True)[0, 0, :2]
+        same = all((np.isnan(g) and np.isnan(w_)) or g.tobytes() == w_.tobytes() for g, w_ in zip(got, want))
+        if not same:
+            bad.append(((a, b), [float(v) for v in got], [float(v) for v in want]))
+    assert not bad, "%s: %d of %d pairs differ, first: %s" % (expr, len(bad), len(SPECIAL_SCALARS) ** 2, bad[:6])
