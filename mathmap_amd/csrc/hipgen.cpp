@@ -147,7 +147,8 @@ struct Generator {
                 return s + "}}";
             }
             case Rhs::Closure: {
-                if (r.filter->kind == Filter::MathMap) return "mm_closure_image(A)";
+                if (r.filter->kind == Filter::MathMap)      // index -2 - id: rendered for a native filter by the runtime
+                    return "mm_closure_image(A, " + std::to_string(stmt ? stmt->closure_id : -1) + ")";
                 auto it = native_index.find(stmt);
                 if (it == native_index.end() || sl != PROLOGUE)
                     throw CompileError("native filter `" + r.filter->name +
@@ -927,8 +928,9 @@ struct Generator {
             out << noise_table_text() << device_noise_prelude() << "\n";
         }
         out << R"(
-MM_DEV mm_image mm_closure_image(const mm_args &A) {
-    mm_image im; im.idx = -1; im.pw = A.img_width; im.ph = A.img_height; im.xf = im.yf = 1.0f; im.resized = 0; return im;
+MM_DEV mm_image mm_closure_image(const mm_args &A, int closure_id) {
+    mm_image im; im.idx = closure_id < 0 ? -1 : -2 - closure_id; im.pw = A.img_width; im.ph = A.img_height;
+    im.xf = im.yf = 1.0f; im.resized = 0; return im;
 }
 struct mm_narg_t { int kind; int i; float f; mm_image img; };
 MM_DEV mm_narg_t mm_narg(int v) { mm_narg_t a; a.kind = 0; a.i = v; a.f = (float)v; a.img = mm_null_image(); return a; }

@@ -388,6 +388,7 @@ void js_block(std::ostringstream &o, const Block &b) {
             case Stmt::Assign:
                 o << "{\"k\":\"assign\",\"lhs\":[" << s->lhs->var->id << "," << s->lhs->index << "],\"rhs\":";
                 js_rhs(o, s->rhs);
+                if (s->closure_id >= 0) o << ",\"cid\":" << s->closure_id;
                 break;
             case Stmt::If:
                 o << "{\"k\":\"if\",\"cond\":"; js_rhs(o, s->cond);
@@ -440,7 +441,13 @@ std::string dump_ir(const FilterCode &code) {
         if (code.result[i]) o << "[" << code.result[i]->var->id << "," << code.result[i]->index << "]";
         else o << "null";
     }
-    o << "]}";
+    o << "]";
+    if (!code.closure_renders.empty()) {
+        o << ",\"closure_renders\":[";
+        for (size_t i = 0; i < code.closure_renders.size(); ++i) { if (i) o << ","; o << dump_ir(*code.closure_renders[i]); }
+        o << "]";
+    }
+    o << "}";
     return o.str();
 }
 

@@ -115,6 +115,10 @@ struct Stmt {
     Stmt *parent = nullptr;
     bool hoisted = false;     // belongs (also) to the frame-constant slice
     bool in_pixel = true;     // belongs (also) to the per-pixel slice
+    // Assign of a MathMap closure that a native filter (or render()) takes as an image: index into
+    // FilterCode::closure_renders, the code that renders it into a float map (render_image's closure
+    // branch, builtins.c:267-302); -1 otherwise
+    int closure_id = -1;
 };
 
 // User-value (filter argument) kinds; numbering is ours, the ABI importer maps.
@@ -156,6 +160,11 @@ struct FilterCode {
     std::deque<Value> values;
     std::deque<Stmt> stmts;
     int next_var = 0, next_val = 0;
+    // One entry per closure image handed to a native filter: the same filter lowered again with its
+    // result replaced by that closure applied at the pixel's own coordinates at t = 0 (what
+    // render_image's calc_lines(..., floatmap = 1) launch computes).  The runtime renders it into the
+    // native filter's input map before the native filter runs.
+    std::vector<std::unique_ptr<FilterCode>> closure_renders;
 
     CompVar *new_var(Ty t, const std::string &name = "", int elem = 0);
     Value *new_value(CompVar *v);

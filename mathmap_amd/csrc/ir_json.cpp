@@ -183,6 +183,7 @@ struct Loader {
                 s->lhs = value(j["lhs"][(size_t)0].i(), j["lhs"][1].i());
                 s->lhs->def = s;
                 s->rhs = rhs(j["rhs"]);
+                if (j["cid"].k == J::Num) s->closure_id = (int)j["cid"].i();
                 s->parent = parent;
                 out.push_back(s);
             } else if (k == "if") {
@@ -201,6 +202,21 @@ struct Loader {
                 block(j["body"], s->body, s);
                 out.push_back(s);
             }
+        }
+    }
+
+    // body, variables and result of a closure-render dump: same filter (user values) as the main code
+    void load_sub(const J &root, Filter *main_filter) {
+        code.filter = main_filter;
+        for (const J &v : root["vars"].arr) {
+            CompVar *cv = code.new_var(type_of(v["type"].str), v["name"].str, (int)v["elem"].i());
+            cv->tuple_len = (int)v["tuple_len"].i();
+            vars[(int)v["id"].i()] = cv;
+        }
+        block(root["body"], code.body, nullptr);
+        for (int i = 0; i < 4; ++i) {
+            const J &r = root["result"][(size_t)i];
+            code.result[i] = value(r[(size_t)0].i(), r[1].i());
         }
     }
 
@@ -231,6 +247,11 @@ struct Loader {
         for (int i = 0; i < 4; ++i) {
             const J &r = root["result"][(size_t)i];
             code.result[i] = value(r[(size_t)0].i(), r[1].i());
+        }
+        for (const J &sub : root["closure_renders"].arr) {
+            code.closure_renders.emplace_back(new FilterCode());
+            Loader ls(mod, *code.closure_renders.back());
+            ls.load_sub(sub, f);
         }
     }
 };

@@ -40,6 +40,12 @@ class Lowerer {
     Lowerer(Module &m, FilterCode &code) : m_(m), code_(code), g_(code) {}
     const std::map<int, Primary> *uv_consts_ = nullptr;
     void run(Filter *f);
+    // closure images handed to native filters (render_image's closure branch)
+    int render_target_ = -1;        // >= 0: lower "closure #render_target_ applied at (x, y), t = 0" as the result
+    int closure_counter_ = 0;       // closures numbered in the order their first native use is lowered
+    bool target_done_ = false, in_target_body_ = false;
+    Value *target_result_[4] = {nullptr, nullptr, nullptr, nullptr};
+    void native_image_argument(CompVar *image);
 
    private:
     Module &m_;
@@ -392,6 +398,35 @@ ImageChain Lowerer::resolve_image(Value *v) {
     return c;
 }
 
+// An image argument of a native filter / of render(): when it is a MathMap closure, the native filter
+// renders it first -- render_image's closure branch (builtins.c:267-302) launches the closure's own
+// calc_lines over the whole frame with floatmap = 1 at frame 0, t = 0.0.  The closure gets a number;
+// lowering the filter again with render_target_ set to that number produces the code of that launch:
+// the closure's body inlined at the pixel's raw coordinates, its values as the filter result.
+void Lowerer::native_image_argument(CompVar *image) {
+    ImageChain ch = resolve_image(image->current);
+    if (ch.base != ImageChain::MathMapClosure) return;
+    Stmt *def = ch.closure_def;
+    if (in_target_body_) return;     // (a closure rendered for a native filter may not feed native filters itself)
+    if (def->closure_id < 0) def->closure_id = closure_counter_++;
+    if (def->closure_id != render_target_ || target_done_) return;
+    if (while_depth_ > 0) throw CompileError("a filter closure passed to a native filter inside a loop is not supported");
+    std::vector<Primary> cargs = def->rhs.args;
+    cargs.push_back(Primary::V(internal_value("x", false)));
+    cargs.push_back(Primary::V(internal_value("y", false)));
+    cargs.push_back(Primary::F(0.0f));                     // invocation_new_frame(invocation, image, 0, 0.0)
+    CompVar *res[4];
+    in_target_body_ = true;          // numbering must not depend on which closure is the target
+    gen_filter(def->rhs.filter, &cargs, res);
+    in_target_body_ = false;
+    for (int i = 0; i < 4; ++i) {
+        target_result_[i] = res[i]->current;
+        const Stmt *d = target_result_[i] ? target_result_[i]->def : nullptr;
+        if (d && d->parent) throw CompileError("a filter closure passed to a native filter inside a conditional is not supported");
+    }
+    target_done_ = true;
+}
+
 // EXPR_FILTER_CLOSURE, compiler.c:2165-2222
 void Lowerer::gen_closure(AstNode *n, CompVar **dest, bool alloced) {
     Filter *callee = n->filter;
@@ -404,6 +439,7 @@ void Lowerer::gen_closure(AstNode *n, CompVar **dest, bool alloced) {
             g_.assign_op(c, "MAKE_COLOR", {g_.P(a[0]), g_.P(a[1]), g_.P(a[2]), g_.P(a[3])});
             prims.push_back(g_.P(c));
         } else if (u.kind == UvKind::Image) {
+            if (callee->kind == Filter::Native) native_image_argument(a[0]);
             CompVar *c = g_.temp(Ty::Image);
             g_.assign_op(c, "STRIP_RESIZE", {g_.P(a[0])});
             prims.push_back(g_.P(c));
@@ -458,6 +494,7 @@ void Lowerer::gen_func(AstNode *n, CompVar **dest, bool alloced) {
             return;
         }
     }
+    if (n->entry->id == "render") native_image_argument(args[0][0]);
     GenScope scope(g_);
     n->entry->gen(g_, args, types, result);
 }
@@ -638,6 +675,10 @@ void Lowerer::run(Filter *f) {
     CompVar *res[4];
     gen_filter(f, nullptr, res);
     for (int i = 0; i < 4; ++i) code_.result[i] = res[i]->current;
+    if (render_target_ >= 0) {
+        if (!target_done_) throw CompileError("internal: closure render target not reached");
+        for (int i = 0; i < 4; ++i) code_.result[i] = target_result_[i];
+    }
 }
 
 }  // namespace
@@ -650,6 +691,16 @@ std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<in
     l.uv_consts_ = uv_consts;
     l.run(f);
     propagate_types(*code);
+    for (int k = 0; k < l.closure_counter_; ++k) {
+        std::unique_ptr<FilterCode> sub(new FilterCode());
+        sub->filter = f;
+        Lowerer ls(m, *sub);
+        ls.uv_consts_ = uv_consts;
+        ls.render_target_ = k;
+        ls.run(f);
+        propagate_types(*sub);
+        code->closure_renders.push_back(std::move(sub));
+    }
     return code;
 }
 

@@ -67,6 +67,18 @@ void mmhip_default_options(mmhip_options *o) {
     o->tile_w = 0;
 }
 
+// kernels of the closure images this filter hands to native filters (FilterCode::closure_renders)
+static void generate_closure_kernels(mmhip_filter *f, const KernelOptions &ko) {
+    f->closures.clear();
+    for (auto &sub : f->code->closure_renders) {
+        mmhip_closure_kernel ck;
+        ck.ks = generate_hip(*sub, ko);
+        if (!ck.ks.natives.empty())
+            throw CompileError("a filter closure that is rendered for a native filter calls native filters itself: not supported");
+        f->closures.push_back(std::move(ck));
+    }
+}
+
 static mmhip_filter *compile_source(const char *source, const mmhip_options *opts, const std::map<int, Primary> *consts) {
     std::unique_ptr<mmhip_filter> f(new mmhip_filter());
     try {
@@ -89,6 +101,11 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
         if (consts) specialize_constants(*f->code);
         optimize(*f->code);
         analyze_frame_constants(*f->code);
+        for (auto &sub : f->code->closure_renders) {
+            if (consts) specialize_constants(*sub);
+            optimize(*sub);
+            analyze_frame_constants(*sub);
+        }
         KernelOptions ko;
         if (opts) {
             ko.intersample = opts->intersample;
@@ -103,6 +120,7 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
         f->kopt = ko;
         f->ir_json = dump_ir(*f->code);
         f->ks = generate_hip(*f->code, ko);
+        generate_closure_kernels(f.get(), ko);
     } catch (const CompileError &e) {
         g_err = e.what();
         if (e.pos >= 0) g_err += " (at offset " + std::to_string(e.pos) + ")";
@@ -149,9 +167,15 @@ bool mmhip_filter_finalize(mmhip_filter *f, const KernelOptions &ko, std::string
         if (f->ir_json_raw.empty()) f->ir_json_raw = dump_ir(*f->code);
         optimize(*f->code);
         analyze_frame_constants(*f->code);
+        for (auto &sub : f->code->closure_renders) {
+            sub->filter = f->module.main;
+            optimize(*sub);
+            analyze_frame_constants(*sub);
+        }
         f->kopt = ko;
         f->ir_json = dump_ir(*f->code);
         f->ks = generate_hip(*f->code, ko);
+        generate_closure_kernels(f, ko);
     } catch (const std::exception &e) {
         *err = e.what();
         return false;
@@ -164,6 +188,7 @@ extern "C" {
 void mmhip_filter_free(mmhip_filter *f) {
     if (!f) return;
     for (auto &p : f->spec_cache) mmhip_filter_free(p.second);
+    for (mmhip_closure_kernel &ck : f->closures) if (ck.mod) (void)hipModuleUnload(ck.mod);
     if (f->mod) (void)hipModuleUnload(f->mod);
     delete f;
 }
@@ -192,62 +217,76 @@ const char *mmhip_filter_kernel_source(mmhip_filter *f) { return f->ks.source.c_
 int mmhip_filter_num_native_calls(const mmhip_filter *f) { return (int)f->ks.natives.size(); }
 double mmhip_filter_jit_seconds(const mmhip_filter *f) { return f->jit_seconds; }
 
+// hiprtc-compiles one kernel source (or fetches it from the on-disk cache); 0 on success
+static int jit_source(const KernelSource &ks, std::vector<char> &code_object) {
+    if (!code_object.empty()) return 0;
+    // extra hiprtc options for experiments (space separated); part of the cache key
+    std::vector<std::string> extra;
+    std::string extra_key;
+    if (const char *e = getenv("MMHIP_HIPRTC_FLAGS")) {
+        std::istringstream is(e);
+        for (std::string w; is >> w;) { extra.push_back(w); extra_key += "_" + std::to_string(std::hash<std::string>()(w) & 0xffff); }
+    }
+    std::string path = cache_dir() + "/" + ks.key + "_o2" + extra_key + ".hsaco";   // _o2: option-set version
+    std::ifstream in(path, std::ios::binary);
+    if (in && !getenv("MMHIP_NO_CACHE")) code_object.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+    if (!code_object.empty()) return 0;
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, ks.source.c_str(), "mathmap_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail("hiprtcCreateProgram failed");
+    // -fno-slp-vectorize: the SLP vectoriser packs scalar f32 chains into v_pk_* at the price of
+    // register shuffles (Mandelbrot's loop: 11 VALU with it, 10 without; measured +9 %); the
+    // fetch path gets its packed math from explicit float2 code instead
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize"};
+    for (const std::string &w : extra) opts.push_back(w.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, 0);
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail("hiprtc compile failed:\n" + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code_object.resize(n);
+    hiprtcGetCode(prog, code_object.data());
+    hiprtcDestroyProgram(&prog);
+    std::string tmp = path + ".tmp" + std::to_string((int)getpid());
+    std::ofstream o(tmp, std::ios::binary);
+    if (o) {
+        o.write(code_object.data(), (std::streamsize)code_object.size());
+        o.close();
+        rename(tmp.c_str(), path.c_str());
+    }
+    return 0;
+}
+
+static int load_kernels(const KernelSource &ks, const std::vector<char> &code_object, hipModule_t *mod, hipFunction_t *f_pix,
+                        hipFunction_t *f_pro) {
+    hipError_t e = hipModuleLoadData(mod, code_object.data());
+    if (e != hipSuccess) return fail(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+    e = hipModuleGetFunction(f_pix, *mod, ks.pixel_name.c_str());
+    if (e != hipSuccess) return fail(std::string("hipModuleGetFunction(pixels): ") + hipGetErrorString(e));
+    e = hipModuleGetFunction(f_pro, *mod, ks.prologue_name.c_str());
+    if (e != hipSuccess) return fail(std::string("hipModuleGetFunction(prologue): ") + hipGetErrorString(e));
+    return 0;
+}
+
 long mmhip_filter_jit(mmhip_filter *f, int load_module) {
     if (f->deferred) return 0;     // kernels are built per user-value set at render time
     auto t0 = std::chrono::steady_clock::now();
-    if (f->code_object.empty()) {
-        // extra hiprtc options for experiments (space separated); part of the cache key
-        std::vector<std::string> extra;
-        std::string extra_key;
-        if (const char *e = getenv("MMHIP_HIPRTC_FLAGS")) {
-            std::istringstream is(e);
-            for (std::string w; is >> w;) { extra.push_back(w); extra_key += "_" + std::to_string(std::hash<std::string>()(w) & 0xffff); }
-        }
-        std::string path = cache_dir() + "/" + f->ks.key + "_o2" + extra_key + ".hsaco";   // _o2: option-set version
-        std::ifstream in(path, std::ios::binary);
-        if (in && !getenv("MMHIP_NO_CACHE")) {
-            f->code_object.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
-        }
-        if (f->code_object.empty()) {
-            hiprtcProgram prog;
-            if (hiprtcCreateProgram(&prog, f->ks.source.c_str(), "mathmap_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-                return fail("hiprtcCreateProgram failed");
-            // -fno-slp-vectorize: the SLP vectoriser packs scalar f32 chains into v_pk_* at the price of
-            // register shuffles (Mandelbrot's loop: 11 VALU with it, 10 without; measured +9 %); the
-            // fetch path gets its packed math from explicit float2 code instead
-            std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                                              "-fno-slp-vectorize"};
-            for (const std::string &w : extra) opts.push_back(w.c_str());
-            hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
-            if (r != HIPRTC_SUCCESS) {
-                size_t n = 0;
-                hiprtcGetProgramLogSize(prog, &n);
-                std::string log(n, 0);
-                if (n) hiprtcGetProgramLog(prog, &log[0]);
-                hiprtcDestroyProgram(&prog);
-                return fail("hiprtc compile failed:\n" + log);
-            }
-            size_t n = 0;
-            hiprtcGetCodeSize(prog, &n);
-            f->code_object.resize(n);
-            hiprtcGetCode(prog, f->code_object.data());
-            hiprtcDestroyProgram(&prog);
-            std::string tmp = path + ".tmp" + std::to_string((int)getpid());
-            std::ofstream o(tmp, std::ios::binary);
-            if (o) {
-                o.write(f->code_object.data(), (std::streamsize)f->code_object.size());
-                o.close();
-                rename(tmp.c_str(), path.c_str());
-            }
-        }
-    }
+    if (jit_source(f->ks, f->code_object) != 0) return -1;
+    for (mmhip_closure_kernel &ck : f->closures)
+        if (jit_source(ck.ks, ck.code_object) != 0) return -1;
     if (load_module && !f->loaded) {
-        hipError_t e = hipModuleLoadData(&f->mod, f->code_object.data());
-        if (e != hipSuccess) return fail(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
-        e = hipModuleGetFunction(&f->f_pix, f->mod, f->ks.pixel_name.c_str());
-        if (e != hipSuccess) return fail(std::string("hipModuleGetFunction(pixels): ") + hipGetErrorString(e));
-        e = hipModuleGetFunction(&f->f_pro, f->mod, f->ks.prologue_name.c_str());
-        if (e != hipSuccess) return fail(std::string("hipModuleGetFunction(prologue): ") + hipGetErrorString(e));
+        if (load_kernels(f->ks, f->code_object, &f->mod, &f->f_pix, &f->f_pro) != 0) return -1;
+        for (mmhip_closure_kernel &ck : f->closures)
+            if (!ck.loaded) {
+                if (load_kernels(ck.ks, ck.code_object, &ck.mod, &ck.f_pix, &ck.f_pro) != 0) return -1;
+                ck.loaded = true;
+            }
         f->loaded = true;
     }
     f->jit_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -306,6 +345,7 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
         d.kind = IMG_NULL;
         inv->images.push_back(d);
     }
+    inv->closure_state.resize(f->closures.size());
     inv->native_maps.assign(f->ks.natives.size(), nullptr);
     inv->native_map_size.assign(f->ks.natives.size(), {0, 0});
     inv->native_gen.assign(f->ks.natives.size(), 0);
@@ -339,6 +379,12 @@ void mmhip_invocation_free(mmhip_invocation *inv) {
     for (void *p : inv->owned) (void)hipFree(p);
     for (void *p : inv->native_maps) if (p) (void)hipFree(p);
     if (inv->ss_lines) (void)hipFree(inv->ss_lines);
+    for (auto &c : inv->closure_state) {
+        if (c.map) (void)hipFree(c.map);
+        if (c.d_xy) (void)hipFree(c.d_xy);
+        if (c.d_xtab) (void)hipFree(c.d_xtab);
+        if (c.d_ytab) (void)hipFree(c.d_ytab);
+    }
     inv->ws.release();
     if (inv->d_uv) (void)hipFree(inv->d_uv);
     if (inv->d_images) (void)hipFree(inv->d_images);
@@ -564,6 +610,68 @@ static int upload_tables(mmhip_invocation *inv, hipStream_t s) {
     return 0;
 }
 
+static int rows_per_item(const KernelSource &ks, int tiles_x, int num_rows) {
+    // rows per work-item: enough workgroups must remain to fill 256 CUs several times over
+    const long wg1 = (long)tiles_x * ((num_rows + ks.tile_h - 1) / ks.tile_h);
+    int ppt = wg1 >= 131072 ? 8 : wg1 >= 32768 ? 4 : wg1 >= 8192 ? 2 : 1;
+    if (const char *e = getenv("MMHIP_PPT")) ppt = std::max(1, atoi(e));
+    if (ks.single_pixel) ppt = 1;
+    const int u = std::max(1, ks.unroll);          // the kernel steps MM_UNROLL rows at a time
+    return (ppt + u - 1) / u * u;
+}
+
+// render_image's closure branch (builtins.c:273-298): closure image #cid of the filter rendered over the
+// whole frame into a float map -- calc_lines(slice 0,0,w,h; first_row 0, last_row h; floatmap = 1) on a
+// frame made by invocation_new_frame(invocation, image, 0, 0.0): frame 0, t = 0, sampling offsets 0.
+static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const HArgs &main_args, hipStream_t s) {
+    mmhip_closure_kernel &ck = f->closures[cid];
+    auto &st = inv->closure_state[cid];
+    const int w = main_args.render_width, h = main_args.render_height;
+    if (st.map && (st.w != w || st.h != h)) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(st.map); st.map = nullptr; }
+    if (!st.map) { HIP_TRY(hipMalloc(&st.map, (size_t)w * h * 16)); st.w = w; st.h = h; }
+    if (w > st.xtab_cap) {
+        if (st.d_xtab) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(st.d_xtab); }
+        HIP_TRY(hipMalloc((void **)&st.d_xtab, (size_t)w * sizeof(float)));
+        st.xtab_cap = w;
+    }
+    if (h > st.ytab_cap) {
+        if (st.d_ytab) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(st.d_ytab); }
+        HIP_TRY(hipMalloc((void **)&st.d_ytab, (size_t)h * sizeof(float)));
+        st.ytab_cap = h;
+    }
+    const int xy_bytes = std::max(ck.ks.xy_bytes, 256);
+    if (xy_bytes > st.xy_cap) {
+        if (st.d_xy) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(st.d_xy); }
+        HIP_TRY(hipMalloc((void **)&st.d_xy, xy_bytes));
+        HIP_TRY(hipMemset(st.d_xy, 0, xy_bytes));
+        st.xy_cap = xy_bytes;
+    }
+    HArgs a = main_args;
+    a.t = 0.0f;
+    a.frame = 0;
+    a.region_x = a.region_y = 0;
+    a.region_width = w;
+    a.region_height = h;
+    a.sampling_offset_x = a.sampling_offset_y = 0.0f;
+    a.first_row = 0;
+    a.num_rows = h;
+    a.output_bpp = 4;
+    a.row_stride = w * 4;
+    a.floatmap = 1;
+    a.out = st.map;
+    a.xtab = st.d_xtab;
+    a.ytab = st.d_ytab;
+    const int tiles_x = (w + ck.ks.tile_w - 1) / ck.ks.tile_w;
+    a.ppt = rows_per_item(ck.ks, tiles_x, h);
+    const int tiles_y = (h + ck.ks.tile_h * a.ppt - 1) / (ck.ks.tile_h * a.ppt);
+    char *xy = st.d_xy;
+    void *params[] = {&a, &xy};
+    const int n = std::max(w, h);
+    HIP_TRY(hipModuleLaunchKernel(ck.f_pro, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(ck.f_pix, (unsigned)((long)tiles_x * tiles_y), 1, 1, 256, 1, 1, 0, s, params, nullptr));
+    return 0;
+}
+
 static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, hipStream_t s, bool *direct_written) {
     std::vector<char> host(f->ks.xy_bytes);
     HIP_TRY(hipMemcpyAsync(host.data(), inv->d_xy, host.size(), hipMemcpyDeviceToHost, s));
@@ -626,13 +734,39 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
             inv->images[slot].data = nullptr;
             table_changed = true;
         }
+        // Closure images among the arguments (index -2 - id, mm_closure_image): rendered into float maps now and
+        // handed to the native filter as such.  The reference gives every closure image a fresh id
+        // (image_new_id), so a call on a closure never hits the cache: always recomputed here too.
+        std::vector<HImageDesc> images_k;                 // inv->images + the rendered closures, only when needed
+        bool has_closure_arg = false;
+        for (int i = 0; i < rec.nargs && i < 4; ++i) {
+            if (rec.args[i].kind != 2 || rec.args[i].img.idx > -2) continue;
+            const int cid = -2 - rec.args[i].img.idx;
+            if (cid >= (int)f->closures.size()) return fail("internal: closure image without a render kernel");
+            if (render_closure(inv, f, cid, a, s) != 0) return -1;
+            if (images_k.empty()) images_k = inv->images;
+            HImageDesc d{};
+            d.data = inv->closure_state[cid].map;
+            d.w = a.render_width;
+            d.h = a.render_height;
+            d.kind = IMG_FLOATMAP;
+            d.num_frames = 1;
+            d.ax = d.bx = (float)((float)(d.w - 1) / 2.0);
+            d.ay = d.by = (float)((float)(d.h - 1) / 2.0);
+            d.ay *= -1.0f;
+            rec.args[i].img.idx = (int)images_k.size();
+            rec.args[i].img.pw = d.w;
+            rec.args[i].img.ph = d.h;
+            images_k.push_back(d);
+            has_closure_arg = true;
+        }
         // generations of the native maps among this call's image arguments (cache.c keys on image ids)
         std::vector<unsigned long long> deps;
         for (int i = 0; i < rec.nargs && i < 4; ++i)
             if (rec.args[i].kind == 2 && rec.args[i].img.idx >= inv->native_slot_base &&
                 rec.args[i].img.idx < inv->native_slot_base + (int)inv->native_gen.size())
                 deps.push_back(inv->native_gen[rec.args[i].img.idx - inv->native_slot_base]);
-        if (inv->native_maps[k] && inv->native_memo_gen[k] == inv->input_generation &&
+        if (!has_closure_arg && inv->native_maps[k] && inv->native_memo_gen[k] == inv->input_generation &&
             memcmp(&inv->native_memo[k], &rec, sizeof rec) == 0 && inv->native_memo_deps[k] == deps &&
             inv->native_rows[k].first <= want_lo && inv->native_rows[k].second >= want_hi)
             continue;
@@ -661,7 +795,7 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         inv->ws.env.edge_y = f->kopt.edge_y;
         inv->ws.env.edge_color_x = inv->edge_color_x;
         inv->ws.env.edge_color_y = inv->edge_color_y;
-        int rc = run_native_filter(f->ks.natives[k].func, rec, inv->images, a.render_width, a.render_height,
+        int rc = run_native_filter(f->ks.natives[k].func, rec, has_closure_arg ? images_k : inv->images, a.render_width, a.render_height,
                                    (float *)inv->native_maps[k], inv->ws, s, &err, &got_lo, &got_hi, dk);
         if (rc != 0) return fail(err);
         inv->native_gen[k] = ++inv->native_gen_counter;
@@ -718,6 +852,10 @@ static mmhip_filter *compile_ir_specialized(const mmhip_filter *f, const std::ma
         load_ir_json(sp->module, *sp->code, (f->ir_json_raw.empty() ? f->ir_json : f->ir_json_raw).c_str());
         bake_uservals(sp->code->body, consts);
         specialize_constants(*sp->code);
+        for (auto &sub : sp->code->closure_renders) {
+            bake_uservals(sub->body, consts);
+            specialize_constants(*sub);
+        }
         std::string err;
         if (!mmhip_filter_finalize(sp, f->kopt, &err)) throw CompileError(err);
     } catch (const std::exception &e) {
@@ -860,15 +998,7 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
         }
     }
     int tiles_x = (region_w + f->ks.tile_w - 1) / f->ks.tile_w;
-    // rows per work-item: enough workgroups must remain to fill 256 CUs several times over
-    {
-        const long wg1 = (long)tiles_x * ((a.num_rows + f->ks.tile_h - 1) / f->ks.tile_h);
-        int ppt = wg1 >= 131072 ? 8 : wg1 >= 32768 ? 4 : wg1 >= 8192 ? 2 : 1;
-        if (const char *e = getenv("MMHIP_PPT")) ppt = std::max(1, atoi(e));
-        if (f->ks.single_pixel) ppt = 1;
-        const int u = std::max(1, f->ks.unroll);          // the kernel steps MM_UNROLL rows at a time
-        a.ppt = (ppt + u - 1) / u * u;
-    }
+    a.ppt = rows_per_item(f->ks, tiles_x, a.num_rows);
     int tiles_y = (a.num_rows + f->ks.tile_h * a.ppt - 1) / (f->ks.tile_h * a.ppt);
     long nwg = (long)tiles_x * tiles_y;
     if (nwg > 0x7fffffffL) return fail("region too large for one launch");

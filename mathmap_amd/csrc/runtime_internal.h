@@ -16,7 +16,18 @@
 
 namespace mm { void load_ir_json(Module &mod, FilterCode &code, const char *json); }   // ir_json.cpp
 
+// The kernels that render closure image #k of a filter into a float map (FilterCode::closure_renders[k]):
+// same user values and images as the owning filter, own code object.
+struct mmhip_closure_kernel {
+    mm::KernelSource ks;
+    std::vector<char> code_object;
+    hipModule_t mod = nullptr;
+    hipFunction_t f_pro = nullptr, f_pix = nullptr;
+    bool loaded = false;
+};
+
 struct mmhip_filter {
+    std::vector<mmhip_closure_kernel> closures;
     mm::Module module;
     std::unique_ptr<mm::FilterCode> code;
     mm::KernelOptions kopt;
@@ -67,6 +78,10 @@ struct mmhip_invocation {
     std::vector<unsigned long long> native_gen;
     std::vector<std::vector<unsigned long long>> native_memo_deps;
     unsigned long long native_gen_counter = 0;
+    // closure images rendered for native filters: float map + the sub-launch's own constant buffer / tables
+    struct ClosureState { void *map = nullptr; int w = 0, h = 0; char *d_xy = nullptr; int xy_cap = 0;
+                          float *d_xtab = nullptr, *d_ytab = nullptr; int xtab_cap = 0, ytab_cap = 0; };
+    std::vector<ClosureState> closure_state;
     void *ss_lines = nullptr;              // the two slices of a supersampled render (own allocation:
     size_t ss_bytes = 0;                   // native filters reallocate `ws` underneath a nested render)
     std::vector<mm::HNativeRec> native_memo;   // args of the call that produced native_maps[k]

@@ -130,7 +130,7 @@ class Gen:
             return "(mmo_tup%d){{%s}}" % (len(r["args"]), ", ".join(self.prim(a) for a in r["args"]))
         if k == "closure":
             if not r["native"]:
-                return "mmo_closure_image(A)"
+                return "mmo_closure_image(A, %d)" % (stmt.get("cid", -1) if stmt else -1)
             slot = self.natives[id(stmt)]
             args = ", ".join(self.prim(a) for a in r["args"])
             fn = {"native_filter_gaussian_blur": "mmo_native_gaussian_blur",
@@ -342,7 +342,7 @@ class _Args(C.Structure):
                 ("edge_behaviour_x", C.c_int), ("edge_behaviour_y", C.c_int), ("edge_color_x", C.c_uint),
                 ("edge_color_y", C.c_uint), ("uservals", C.POINTER(_Userval)), ("images", C.POINTER(_ImageDesc)),
                 ("num_images", C.c_int), ("native_slot_base", C.c_int), ("memo", C.POINTER(_Memo)),
-                ("curves", C.c_void_p), ("gradients", C.c_void_p)]
+                ("curves", C.c_void_p), ("gradients", C.c_void_p), ("closure_base", C.c_int)]
 
 
 def _run(cmd):
@@ -432,6 +432,9 @@ class CpuFilter:
                  ["-o", ofile, cfile])
             _run(["gcc", "-shared", "-o", so + ".tmp", ofile] + rt + noise + ["-lm"])
             os.replace(so + ".tmp", so)
+        # closure images handed to native filters: each is rendered by its own code (render_image's closure
+        # branch launches the closure's calc_lines), the IR dump carries that code under "closure_renders"
+        self.subs = [CpuFilter(sub, extra_cflags) for sub in self.ir.get("closure_renders", [])]
         self.lib = C.CDLL(so)
         self.lib.mmo_xy_size.restype = C.c_int
         self.lib.mmo_init_frame.argtypes = [C.POINTER(_Args), C.c_void_p]
@@ -447,6 +450,7 @@ class CpuFilter:
         import time
         uservals = uservals or {}
         images = images or {}
+        a_img_w, a_img_h = width, height
         infos = self.ir["uservals"]
         n_uv = max(len(infos), 1)
         uv = (_Userval * n_uv)()
@@ -497,6 +501,21 @@ class CpuFilter:
             d = _ImageDesc()
             d.kind = 2
             descs.append(d)
+        closure_base = -1
+        if self.subs:
+            # builtins.c:273-298: frame 0, t = 0.0, the whole frame, sampling offsets 0, float map output
+            closure_base = len(descs)
+            for sub in self.subs:
+                m = sub.render(a_img_w, a_img_h, uservals=uservals, images=images, t=0.0, frame=0, intersample=intersample,
+                               floatmap=True, edge=edge, edge_colors=edge_colors, supersampling=supersampling,
+                               render_size=render_size)
+                keep.append(m)
+                d = _ImageDesc()
+                d.data, d.w, d.h, d.kind, d.num_frames, d.channels = m.ctypes.data, m.shape[1], m.shape[0], 1, 1, 4
+                d.ax = d.bx = np.float32(np.float32(d.w - 1) / 2.0)          # floatmap.c:39-41
+                d.by = np.float32(np.float32(d.h - 1) / 2.0)
+                d.ay = np.float32(np.float64(d.by) * -1.0)
+                descs.append(d)
         if not descs:
             d = _ImageDesc()
             d.kind = 2
@@ -524,6 +543,7 @@ class CpuFilter:
         ctab = np.ascontiguousarray(np.concatenate(curves).astype(np.float32)) if curves else np.zeros(1, np.float32)
         gtab = np.ascontiguousarray(np.concatenate(grads).astype(np.uint32)) if grads else np.zeros(1, np.uint32)
         a.curves, a.gradients = ctab.ctypes.data, gtab.ctypes.data
+        a.closure_base = closure_base
         out = np.zeros((height, rw, 4), np.float32) if floatmap else np.zeros((height, rw, bpp), np.uint8)
         xy = C.create_string_buffer(max(self.lib.mmo_xy_size(), 16))
         r0, r1 = rows if rows is not None else (0, height)

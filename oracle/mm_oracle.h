@@ -87,6 +87,7 @@ typedef struct {
     mmo_native_memo *memo;       /* one per native slot */
     const float *curves;
     const color_t *gradients;
+    int closure_base;            /* image-table slot of closure image #0 rendered for native filters, or -1 */
 } mmo_args;
 
 /* ---- op macros (opmacros.h) ---- */
@@ -157,7 +158,7 @@ typedef struct {
 
 mmo_image mmo_image_from_table(const mmo_args *A, int idx);
 mmo_image mmo_null_image(void);
-mmo_image mmo_closure_image(const mmo_args *A);
+mmo_image mmo_closure_image(const mmo_args *A, int closure_id);
 mmo_image mmo_resize_image(mmo_image i, float xf, float yf);
 mmo_image mmo_strip_resize(mmo_image i);
 mmo_tup4 mmo_tuple_from_color(color_t c);

@@ -24,11 +24,16 @@ mmo_image mmo_null_image(void) {
     return im;
 }
 
-/* ALLOC_CLOSURE_IMAGE + cc.c:189: a closure image has the canvas pixel size */
-mmo_image mmo_closure_image(const mmo_args *A) {
+/* ALLOC_CLOSURE_IMAGE + cc.c:189: a closure image has the canvas pixel size.  A closure that a native
+ * filter takes as its input was rendered beforehand (render_image's closure branch, builtins.c:273-298:
+ * the closure's own calc_lines over the frame, floatmap = 1, frame 0, t = 0) by the harness, which runs
+ * the closure's code as a filter of its own (oracle/ccgen.py CpuFilter.subs); its float map sits in the
+ * image table at closure_base + closure_id. */
+mmo_image mmo_closure_image(const mmo_args *A, int closure_id) {
     mmo_image im = {-1, 0, 0, 1.0f, 1.0f, 0};
     im.pw = A->img_width;
     im.ph = A->img_height;
+    if (closure_id >= 0 && A->closure_base >= 0) im.idx = A->closure_base + closure_id;
     return im;
 }
 

@@ -1,0 +1,100 @@
+"""Native filters and render() applied to closure images -- render_image's closure branch
+(builtins/builtins.c:267-302): the closure's own calc_lines is launched over the whole frame with
+floatmap = 1 at frame 0, t = 0.0, and the native filter works on that float map.  HIP (through the
+C ABI) against the oracle, which runs the closure's code as a filter of its own."""
+import numpy as np
+import pytest
+
+import mathmap_amd as mm
+from mathmap_amd import workloads as W
+from oracle.ccgen import CpuFilter
+from tests.gpu_util import make_invocation, render_device, stats
+
+pytestmark = pytest.mark.gpu
+
+INNER = """
+filter inner (image in, float k: 0-2 (1.0))
+  in(xy * k) * 0.8 + rgba:[t * 0.5, 0, 0.1, 0]
+end
+"""
+
+BLUR_OF_CLOSURE = INNER + """
+filter outer (image in, float s: 0-1 (0.03), float k: 0-2 (0.7))
+  b = gaussian_blur(inner(in, k), s, s);
+  b(xy)
+end
+"""
+
+RENDER_OF_CLOSURE = INNER + """
+filter outer (image in, float k: 0-2 (0.7))
+  rendered = render(inner(in, k));
+  rendered(xy * 0.9) * 0.5 + rendered(xy) * 0.5
+end
+"""
+
+CONVOLVE_OF_CLOSURE = INNER + """
+filter outer (image in, image kernel, float k: 0-2 (0.7))
+  c = convolve(inner(in, k), kernel, 1, 0);
+  c(xy)
+end
+"""
+
+TWO_CLOSURES = INNER + """
+filter tint (image in, float g: 0-1 (0.5))
+  in(xy) * rgba:[1, g, 1, 1]
+end
+
+filter outer (image in, float s: 0-1 (0.02), float k: 0-2 (0.7))
+  first = gaussian_blur(inner(in, k), s, s);
+  second = gaussian_blur(tint(in, k * 0.5), s * 2, s);
+  first(xy) * 0.5 + second(xy) * 0.5
+end
+"""
+
+
+@pytest.mark.parametrize("name,src,tol", [("blur", BLUR_OF_CLOSURE, 0), ("render", RENDER_OF_CLOSURE, 0),
+                                          ("two", TWO_CLOSURES, 0)])
+def test_native_filter_on_closure_image(name, src, tol):
+    w, h = 212, 131
+    img = W.synthetic_image(w, h, seed=3)
+    flt, inv = make_invocation(src, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for k, t in ((0.7, 0.0), (1.3, 0.6), (1.3, 0.2), (0.4, 0.9)):
+        inv.set("k", k)
+        got = inv.render(t=t)
+        want = cf.render(w, h, uservals={"k": k}, images={"in": img}, t=t)
+        mx, nd, n1 = stats(got, want)
+        assert mx <= tol, (name, k, t, mx, nd, n1)
+    # the closure is rendered at t = 0 whatever the frame's t (invocation_new_frame(invocation, image, 0, 0.0))
+    if name == "blur":
+        assert np.array_equal(inv.render(t=0.1), inv.render(t=0.8))
+    # row bands and a float-map render go through the same path
+    full = inv.render(t=0.3)
+    banded = render_device(inv, w, h, rows=[(0, 50), (50, 51), (51, h)], t=0.3)
+    assert np.array_equal(full, banded)
+
+
+def test_convolve_on_closure_image():
+    w, h = 96, 64
+    img = W.synthetic_image(w, h, seed=3)
+    yy, xx = np.mgrid[0:h, 0:w]
+    blob = np.exp(-(((xx - w // 2) / 3.0) ** 2 + ((yy - (h // 2 - 1)) / 2.0) ** 2))
+    kern = np.repeat((blob * 255).astype(np.uint8)[:, :, None], 3, axis=2)
+    flt, inv = make_invocation(CONVOLVE_OF_CLOSURE, w, h, {}, {"in": img, "kernel": kern})
+    got = inv.render(t=0.4)
+    want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img, "kernel": kern}, t=0.4)
+    assert stats(got, want)[0] <= 1, stats(got, want)
+
+
+def test_closure_render_survives_an_ir_round_trip():
+    """The IR dump carries the closure's render code ("closure_renders"): a filter rebuilt from it
+    (mmhip_compile_ir_json, what the reference-ABI tier and the fixtures use) renders the same frame."""
+    w, h = 128, 80
+    img = W.synthetic_image(w, h, seed=5)
+    flt, inv = make_invocation(BLUR_OF_CLOSURE, w, h, {"k": 1.1}, {"in": img})
+    a = inv.render(t=0.5)
+    flt2 = mm.Filter("", ir_json=flt.ir_json_raw)
+    inv2 = flt2.invoke(w, h)
+    inv2.set("k", 1.1)
+    inv2.set_image("in", img)
+    assert np.array_equal(a, inv2.render(t=0.5))
