@@ -948,6 +948,9 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
     im.xf = im.yf = 1.0f; im.resized = 0;
     return im;
 }
+// (float) frame column / row of the pixel being evaluated (render_image's per-pixel loop, builtins.c:324-333)
+#define __colF ((float)(col + A.region_x))
+#define __rowF ((float)(rl + A.first_row))
 #define MM_INTERNALS \
     const float t = A.t; const float R = A.R; const int frame = A.frame; \
     const int __canvasPixelW = A.img_width, __canvasPixelH = A.img_height; \

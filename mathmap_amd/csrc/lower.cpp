@@ -45,7 +45,7 @@ class Lowerer {
     int closure_counter_ = 0;       // closures numbered in the order their first native use is lowered
     bool target_done_ = false, in_target_body_ = false;
     Value *target_result_[4] = {nullptr, nullptr, nullptr, nullptr};
-    void native_image_argument(CompVar *image);
+    void native_image_argument(CompVar *image, bool stripped);
 
    private:
     Module &m_;
@@ -403,7 +403,14 @@ ImageChain Lowerer::resolve_image(Value *v) {
 // calc_lines over the whole frame with floatmap = 1 at frame 0, t = 0.0.  The closure gets a number;
 // lowering the filter again with render_target_ set to that number produces the code of that launch:
 // the closure's body inlined at the pixel's raw coordinates, its values as the filter result.
-void Lowerer::native_image_argument(CompVar *image) {
+//
+// `stripped`: the native filter sees the image without its resize wrapper (native filters proper: their image
+// arguments go through STRIP_RESIZE).  render() does not strip: what it gets for a closure made in a filter
+// with the default (unit, square) coordinates is an IMAGE_RESIZE of the closure, which render_image treats
+// like a drawable -- its else branch (builtins.c:303-343) walks the pixels and evaluates
+// ORIG_VAL(fx, fy, image, 0.0) with fx = ((float)x - bx) / ax in float arithmetic, the resize factors
+// applied by the macro (opmacros.h:203-207).  Same result type, slightly different coordinates.
+void Lowerer::native_image_argument(CompVar *image, bool stripped) {
     ImageChain ch = resolve_image(image->current);
     if (ch.base != ImageChain::MathMapClosure) return;
     Stmt *def = ch.closure_def;
@@ -412,9 +419,38 @@ void Lowerer::native_image_argument(CompVar *image) {
     if (def->closure_id != render_target_ || target_done_) return;
     if (while_depth_ > 0) throw CompileError("a filter closure passed to a native filter inside a loop is not supported");
     std::vector<Primary> cargs = def->rhs.args;
-    cargs.push_back(Primary::V(internal_value("x", false)));
-    cargs.push_back(Primary::V(internal_value("y", false)));
-    cargs.push_back(Primary::F(0.0f));                     // invocation_new_frame(invocation, image, 0, 0.0)
+    if (stripped || ch.factors.empty()) {
+        cargs.push_back(Primary::V(internal_value("x", false)));
+        cargs.push_back(Primary::V(internal_value("y", false)));
+    } else {
+        // floatmap.c:39-41: ax = bx = (float)(w - 1) / 2.0, by = (float)(h - 1) / 2.0, ay = by * -1.0
+        CompVar *w = g_.temp(), *h = g_.temp(), *w1 = g_.temp(), *h1 = g_.temp(), *ax = g_.temp(), *by = g_.temp(), *ay = g_.temp();
+        CompVar *cf = g_.temp(), *rf = g_.temp(), *dx = g_.temp(), *dy = g_.temp(), *fx = g_.temp(), *fy = g_.temp();
+        g_.assign(w, Rhs::Int("__renderPixelW"));
+        g_.assign(h, Rhs::Int("__renderPixelH"));
+        g_.assign_op(w1, "SUB", {g_.P(w), Primary::I(1)});
+        g_.assign_op(h1, "SUB", {g_.P(h), Primary::I(1)});
+        g_.assign_op(ax, "DIV", {g_.P(w1), Primary::I(2)});
+        g_.assign_op(by, "DIV", {g_.P(h1), Primary::I(2)});
+        g_.assign_op(ay, "NEG", {g_.P(by)});
+        g_.assign(cf, Rhs::Int("__colF"));                // (float)column of the pixel in the frame
+        g_.assign(rf, Rhs::Int("__rowF"));
+        g_.assign_op(dx, "SUB", {g_.P(cf), g_.P(ax)});
+        g_.assign_op(dy, "SUB", {g_.P(rf), g_.P(by)});
+        g_.assign_op(fx, "DIV", {g_.P(dx), g_.P(ax)});
+        g_.assign_op(fy, "DIV", {g_.P(dy), g_.P(ay)});
+        CompVar *x = fx, *y = fy;
+        for (auto &fac : ch.factors) {                    // opmacros.h:203-207, one wrapper per resize
+            CompVar *nx = g_.temp(), *ny = g_.temp();
+            g_.assign_op(nx, "MUL", {g_.P(x), fac.first});
+            g_.assign_op(ny, "MUL", {g_.P(y), fac.second});
+            x = nx;
+            y = ny;
+        }
+        cargs.push_back(g_.P(x));
+        cargs.push_back(g_.P(y));
+    }
+    cargs.push_back(Primary::F(0.0f));                     // frame 0 / t = 0.0 in both branches
     CompVar *res[4];
     in_target_body_ = true;          // numbering must not depend on which closure is the target
     gen_filter(def->rhs.filter, &cargs, res);
@@ -439,7 +475,7 @@ void Lowerer::gen_closure(AstNode *n, CompVar **dest, bool alloced) {
             g_.assign_op(c, "MAKE_COLOR", {g_.P(a[0]), g_.P(a[1]), g_.P(a[2]), g_.P(a[3])});
             prims.push_back(g_.P(c));
         } else if (u.kind == UvKind::Image) {
-            if (callee->kind == Filter::Native) native_image_argument(a[0]);
+            if (callee->kind == Filter::Native) native_image_argument(a[0], true);
             CompVar *c = g_.temp(Ty::Image);
             g_.assign_op(c, "STRIP_RESIZE", {g_.P(a[0])});
             prims.push_back(g_.P(c));
@@ -494,7 +530,7 @@ void Lowerer::gen_func(AstNode *n, CompVar **dest, bool alloced) {
             return;
         }
     }
-    if (n->entry->id == "render") native_image_argument(args[0][0]);
+    if (n->entry->id == "render") native_image_argument(args[0][0], false);
     GenScope scope(g_);
     n->entry->gen(g_, args, types, result);
 }

@@ -266,7 +266,7 @@ void optimize(FilterCode &code) {
 // ---------------------------------------------------------------------------
 namespace {
 
-bool internal_is_frame_const(const std::string &n) { return n != "x" && n != "y"; }
+bool internal_is_frame_const(const std::string &n) { return n != "x" && n != "y" && n != "__colF" && n != "__rowF"; }
 
 }  // namespace
 

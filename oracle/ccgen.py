@@ -297,7 +297,9 @@ void mmo_init_frame(const mmo_args *A, void *xyv) {
     for (col = 0; col < A->region_width; ++col) {
       float x = CALC_VIRTUAL_X(col + A->region_x, A->frame_render_width, A->sampling_offset_x);
       float rt[4];
+      const float __colF = (float)(col + A->region_x), __rowF = (float)(row + A->region_y);
       unsigned mm_rand_ctr = 0;
+      (void)__colF; (void)__rowF;
       (void)x; (void)y; (void)mm_rand_ctr;""")
         self.decls(pix_defs, "      ", out)
         self.stmts(ir["body"], False, "      ", out)

@@ -465,7 +465,17 @@ mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h) {
     mmo_image_desc *dst = &A->images[A->native_slot_base + slot];
     mmo_image out;
     const mmo_image_desc *src = &A->images[in.idx];
-    if (src->kind == MMO_IMG_FLOATMAP) return in;
+    if (src->kind == MMO_IMG_FLOATMAP) {
+        /* a closure the harness rendered beforehand: render_image made a new, plain float map of it
+         * (no resize wrapper on the result, builtins.c:270-271,345) */
+        if (A->closure_base >= 0 && in.idx >= A->closure_base) {
+            in.pw = src->w;
+            in.ph = src->h;
+            in.xf = in.yf = 1.0f;
+            in.resized = 0;
+        }
+        return in;
+    }
     if (!(m->valid && m->func == 2 && m->in_idx == in.idx && m->w == w && m->h == h)) {
         if (m->map == NULL || m->w != w || m->h != h) {
             free(m->map);
