@@ -34,8 +34,8 @@ NUM_FRAMES = 120                        # BASELINE config 5: 120-frame animation
 def frame_t(frame):
     """t of animation frame `frame` as the CLI computes it: (float)frame / (float)num_frames
     (mathmap_cmdline.c:835)."""
-    import numpy as np
-    return float(np.float32(frame % NUM_FRAMES) / np.float32(NUM_FRAMES))
+    from mathmap_amd.striping import animation_frame_t
+    return animation_frame_t(frame % NUM_FRAMES, NUM_FRAMES)
 
 
 def device_image(torch, w, h):

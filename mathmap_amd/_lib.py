@@ -83,10 +83,30 @@ BACKEND_SYMBOLS = {
     "mathmap_hip_set_get_pixel": (None, [C.c_void_p]),
     "mathmap_hip_invalidate_drawable": (None, [C.c_void_p]),
     "mathmap_hip_release_invocation": (None, [C.c_void_p]),
+}
+
+# test scaffolding of the reference-ABI tier: tests/libmathmap_hip_selftest.so (built from csrc/abi_selftest.cpp,
+# linked against the product library; not part of it)
+SELFTEST_SYMBOLS = {
     "mmhip_selftest_abi_roundtrip": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "mmhip_selftest_error": (C.c_char_p, []),
 }
+SELFTEST_PATH = os.path.join(os.path.dirname(_HERE), "tests", "libmathmap_hip_selftest.so")
+_selftest = None
+
+
+def selftest_lib():
+    global _selftest
+    if _selftest is None:
+        lib()
+        l = C.CDLL(SELFTEST_PATH)
+        for name, (res, args) in SELFTEST_SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _selftest = l
+    return _selftest
 
 _lib = None
 

@@ -16,6 +16,13 @@ test_gauss_row_stripes_with_local_halo_equal_full_frame checks bit-equality with
 """
 
 
+def animation_frame_t(frame, num_frames):
+    """t of frame `frame` of a `num_frames`-frame animation, as the reference's command line computes
+    it: (float)frame / (float)num_frames in float arithmetic (mathmap_cmdline.c:835)."""
+    import numpy as np
+    return float(np.float32(frame) / np.float32(num_frames))
+
+
 def stripe_rows(height, rank, world):
     """Rows [lo, hi) of rank `rank` out of `world`: the reference's band formula."""
     lo = height * rank // world

@@ -1,10 +1,17 @@
-"""The benchmark / parity workloads, written in the .mm filter language.
+"""The benchmark / parity workloads, in the .mm filter language.
 
-These are this project's own statements of the five BASELINE.json configurations
-(the reference keeps equivalent scripts under examples/; tests/test_workloads.py
-checks, where the reference tree is available, that each text below compiles to
-code whose output is identical to the reference script's).  User-value names are
-kept because they are the filters' public interface (``-Dname=value``).
+Provenance, plainly: these are the reference's own example scripts -- the input programs that
+BASELINE.json names (examples/Utilities/Ident.mm, examples/Render/Mandelbrot.mm,
+examples/Distorts/Pond.mm, examples/Blur/Gaussian Blur.mm, examples/Map/Droste.mm, and
+tests/{Apply,Circle,Closure,Twice}.mm) -- retyped with local variables renamed and comments
+reworded.  They are not independent work: the algorithms, the user-value names (the filters'
+public interface, ``-Dname=value``) and the statement structure are the reference's.  They are
+kept in the tree only because the GPU box has no reference tree to read them from; where the
+reference is present, tests/test_cpu_suite.py::test_workload_text_equals_reference_script renders
+each text and the reference script it restates and requires identical output, and the GPU suite
+additionally runs every reference script from its compiled IR (tests/golden/ir*/, made by
+tests/make_ir_fixtures.py).  GAUSS_DIRECT, CLOSURE_*, CURVE_GRADIENT, TREE_VECTOR, RECURSIVE,
+CONVOLVE, HALF_CONVOLVE and VISUALIZE_FFT are small test filters written for this project.
 """
 
 # config 0: examples/Utilities/Ident -- plumbing: output = input sampled at xy
@@ -59,8 +66,8 @@ stretched filter gauss_direct (stretched image in, float hdev: 0-1 (0.01), float
 end
 """
 
-# config 2: examples/Map/Droste -- Escher's Droste effect (log-polar twist of an annulus,
-# after the Leys / Breic formulation used by the reference example).
+# config 2: examples/Map/Droste.mm of the reference (Escher's Droste effect after Leys / Breic), restated
+# statement by statement with locals renamed (r1 -> rin, retwist -> twist, colorSoFar -> acc ...).
 DROSTE = """
 pixel
 filter droste (pixel image in,

@@ -363,8 +363,9 @@ def build_runtime():
         obj = os.path.join(BUILD, name + ".o")
         src = os.path.join(HERE, name + ".c")
         if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-o", obj + ".tmp", src])
-            os.replace(obj + ".tmp", obj)
+            tmp = "%s.%d.tmp" % (obj, os.getpid())
+            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-o", tmp, src])
+            os.replace(tmp, obj)
         objs.append(obj)
     return objs
 
@@ -375,8 +376,9 @@ def runtime_library():
     rt = build_runtime()
     so = os.path.join(BUILD, "libmm_oracle_rt.so")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in rt):
-        _run(["gcc", "-shared", "-o", so + ".tmp"] + rt + ["-lm"])
-        os.replace(so + ".tmp", so)
+        tmp = "%s.%d.tmp" % (so, os.getpid())
+        _run(["gcc", "-shared", "-o", tmp] + rt + ["-lm"])
+        os.replace(tmp, so)
     return C.CDLL(so)
 
 
@@ -425,15 +427,22 @@ class CpuFilter:
         rt = build_runtime()
         so = os.path.join(BUILD, "f_%s.so" % key)
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in rt):
-            cfile = os.path.join(BUILD, "f_%s.c" % key)
-            ofile = os.path.join(BUILD, "f_%s.o" % key)
+            # per-process intermediate names + atomic rename: several ranks may build the same filter at once
+            cfile = os.path.join(BUILD, "f_%s.%d.c" % (key, os.getpid()))
+            ofile = os.path.join(BUILD, "f_%s.%d.o" % (key, os.getpid()))
             with open(cfile, "w") as f:
                 f.write(self.source)
             # the reference's CGEN_CC / CGEN_LD (Makefile:58-60)
             _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE] + LIBM_NO_BUILTIN + list(extra_cflags) +
                  ["-o", ofile, cfile])
-            _run(["gcc", "-shared", "-o", so + ".tmp", ofile] + rt + noise + ["-lm"])
-            os.replace(so + ".tmp", so)
+            tmp_so = "%s.%d.tmp" % (so, os.getpid())
+            _run(["gcc", "-shared", "-o", tmp_so, ofile] + rt + noise + ["-lm"])
+            os.replace(tmp_so, so)
+            for f in (cfile, ofile):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
         # closure images handed to native filters: each is rendered by its own code (render_image's closure
         # branch launches the closure's calc_lines), the IR dump carries that code under "closure_renders"
         self.subs = [CpuFilter(sub, extra_cflags) for sub in self.ir.get("closure_renders", [])]

@@ -376,7 +376,7 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     structures (include/mathmap_abi.h) the way mathmap_common.c drives the cc backend,
     must produce the same frame as the standalone C API."""
     import ctypes as C
-    from mathmap_amd._lib import lib
+    from mathmap_amd._lib import lib, selftest_lib
     w, h = 256, 256
     src = W.ALL[name]
     needs = "image in" in src
@@ -390,10 +390,10 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     want = inv.render(t=0.25)   # gaussian_blur: default dev = 0 -> sigma 0 -> FIR path with both passes skipped
     got = np.zeros((h, w, 4), np.uint8)
     img = np.ascontiguousarray(marlene)
-    rc = lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p) if needs else None,
+    rc = selftest_lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p) if needs else None,
                                             img.shape[1], img.shape[0], 3, w, h, 0.25, bands,
                                             got.ctypes.data_as(C.c_void_p))
-    assert rc == 0, lib().mmhip_selftest_error().decode()
+    assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
     assert np.array_equal(got, want)
 
 
@@ -403,7 +403,7 @@ def test_reference_abi_tier_specialises_from_the_second_frame(marlene):
     frame must equal the standalone render at its t."""
     import ctypes as C
     import os
-    from mathmap_amd._lib import lib
+    from mathmap_amd._lib import lib, selftest_lib
     w, h = 256, 256
     for name in ("mandelbrot", "pond"):
         src = W.ALL[name]
@@ -416,12 +416,12 @@ def test_reference_abi_tier_specialises_from_the_second_frame(marlene):
         img = np.ascontiguousarray(marlene)
         os.environ["MMHIP_SELFTEST_WARM_FRAMES"] = "2"
         try:
-            rc = lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p) if needs else None,
+            rc = selftest_lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p) if needs else None,
                                                     img.shape[1], img.shape[0], 3, w, h, 0.5, 2,
                                                     got.ctypes.data_as(C.c_void_p))
         finally:
             del os.environ["MMHIP_SELFTEST_WARM_FRAMES"]
-        assert rc == 0, lib().mmhip_selftest_error().decode()
+        assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
         assert np.array_equal(got, want), name
 
 

@@ -28,6 +28,26 @@ WORKER = textwrap.dedent("""
     out = gather_stripes(stripe, h, rank, world)
     if rank == 0:
         np.save(sys.argv[1], out.numpy())
+    # BASELINE config 5 in small: frames of the 120-frame Pond animation, every frame row-striped across the
+    # ranks, t by the CLI's convention; and the blur, whose stripe is its own rows only (what
+    # native_row_margin = 0 asks of the GPU blur -- here the oracle's sampled-row blur stands in)
+    from mathmap_amd.striping import animation_frame_t
+    from oracle.ccgen import gauss_rows
+    pw, ph = 120, 77
+    img = W.synthetic_image(pw, ph, seed=2)
+    pond = CpuFilter(mm.Filter(W.POND).ir_json_raw)
+    lo, hi = stripe_rows(ph, rank, world)
+    frames = []
+    for k in (0, 37, 119):
+        t = animation_frame_t(k, 120)
+        part = pond.render(pw, ph, images={"in": img}, rows=(lo, hi), t=t, frame=k)
+        frames.append(gather_stripes(torch.from_numpy(np.ascontiguousarray(part[lo:hi])), ph, rank, world))
+    dev = np.float32(2 * 3.0 / (pw - 1))
+    fm = gauss_rows(img, dev, dev, list(range(lo, hi)))
+    c = np.where(fm > 0, np.minimum(fm, np.float32(1.0)), np.float32(0.0)).astype(np.float64)
+    blur = gather_stripes(torch.from_numpy((c * 255.0).astype(np.uint8)), ph, rank, world)
+    if rank == 0:
+        np.savez(sys.argv[1] + ".anim.npz", f0=frames[0].numpy(), f37=frames[1].numpy(), f119=frames[2].numpy(), blur=blur.numpy())
     # input replication (scatter + all-gather): every rank ends up with rank 0's image
     ih, iw = 37, 53
     src_img = torch.arange(ih * iw, dtype=torch.int32).view(ih, iw) * 2654435 if rank == 0 else None
@@ -53,3 +73,18 @@ def test_two_rank_stripes_reassemble(tmp_path):
     from oracle.ccgen import CpuFilter
     want = CpuFilter(mm.Filter(W.MANDELBROT).ir_json_raw).render(96, 67)
     assert np.array_equal(np.load(out), want)
+    # the striped animation frames and the striped blur equal single full-frame renders
+    from mathmap_amd.striping import animation_frame_t
+    anim = np.load(str(out) + ".anim.npz")
+    pw, ph = 120, 77
+    img = W.synthetic_image(pw, ph, seed=2)
+    pond = CpuFilter(mm.Filter(W.POND).ir_json_raw)
+    for k in (0, 37, 119):
+        t = animation_frame_t(k, 120)
+        assert t == float(np.float32(k) / np.float32(120))
+        assert np.array_equal(anim["f%d" % k], pond.render(pw, ph, images={"in": img}, t=t, frame=k)), k
+    assert not np.array_equal(anim["f37"], anim["f119"])
+    dev = float(np.float32(2 * 3.0 / (pw - 1)))
+    gd = mm.Filter(W.GAUSS_DIRECT)
+    full = CpuFilter(gd.ir_json_raw).render(pw, ph, uservals={"hdev": dev, "vdev": dev}, images={"in": img})
+    assert np.array_equal(anim["blur"], full)
