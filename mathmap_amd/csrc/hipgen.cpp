@@ -105,6 +105,7 @@ struct Generator {
                         default: return "0";
                     }
                 }
+                if (pair_uniform.count(v)) return "u" + vname(v);      // pair mode: wave-uniform loop value kept as a scalar
                 return vname(v);
             }
             case Primary::IntConst: return p.i < 0 ? "(" + std::to_string(p.i) + ")" : std::to_string(p.i);
@@ -579,6 +580,7 @@ struct Generator {
     std::string pbool(const Primary &p) {        // operand as mm_bb
         if (p.kind == Primary::IntConst) return p.i ? "mm_bb{true, true}" : "mm_bb{false, false}";
         if (p.kind == Primary::Val && p.value->index < 0) return "mm_bb{false, false}";
+        if (pair_uniform.count(p.value)) return "mm_bb{(bool)u" + vname(p.value) + ", (bool)u" + vname(p.value) + "}";
         if (pair_bools.count(p.value)) return vname(p.value);
         return "mm_tob(" + pprim(p, Ty::Int) + ")";
     }
@@ -587,6 +589,8 @@ struct Generator {
         if (p.kind == Primary::IntConst) return std::string(w) + std::to_string(p.i) + ")";
         if (p.kind == Primary::FloatConst) return std::string(w) + float_literal(p.f) + "f)";
         if (p.value->index < 0) return std::string(w) + "0)";
+        if (pair_uniform.count(p.value))
+            return std::string(w) + (p.value->var->type == Ty::Float ? "(float)u" : "(int)u") + vname(p.value) + ")";
         return std::string(w) + vname(p.value) + ")";
     }
     static Ty pair_arith_ty(const Rhs &r) {
@@ -679,12 +683,76 @@ struct Generator {
     std::string pval_as(const Primary &p, const Value *lhs) {      // operand in the representation of `lhs`
         return pair_bools.count(lhs) ? pbool(p) : pprim(p, lhs->var->type);
     }
+    // Wave-uniform values inside a pair-mode loop.  A loop phi that starts from a literal or a frame constant
+    // and is stepped by one -- `n = n + 1`, the iteration counter of every escape-time filter -- holds the same
+    // value in every lane and in both pixels for as long as they are in the loop, and so does everything
+    // computed from such values and loop-invariant scalars alone (`n + 1`, `n < 31`).  Those are kept as plain
+    // scalars (the compiler holds them in SGPRs and evaluates them on the scalar unit: uniform inside a loop
+    // with divergent exits) instead of as per-lane pairs; the per-pixel copy a phi needs after the loop is one
+    // select per iteration instead of an add, a compare and a select.  Values of pixels that have left the loop
+    // are don't-cares inside it, exactly as before.
+    std::set<const Value *> pair_uniform;
+    bool pair_invariant_scalar(const Primary &p) const {
+        if (p.kind == Primary::IntConst || p.kind == Primary::FloatConst) return true;
+        if (p.kind != Primary::Val) return false;
+        return p.value->index < 0 || !pair_defs.count(p.value);          // uninitialised (0) or a frame constant
+    }
+    bool pair_uniform_operand(const Primary &p) const {
+        return pair_invariant_scalar(p) || (p.kind == Primary::Val && pair_uniform.count(p.value));
+    }
+    void pair_mark_uniform(const Block &b) {      // forward pass over a loop body (SSA: definitions precede uses)
+        for (const Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            if (s->kind == Stmt::Assign && s->rhs.kind != Rhs::Internal) {
+                bool ok = s->rhs.kind == Rhs::Prim ? pair_uniform_operand(s->rhs.prim) : s->rhs.kind == Rhs::Op;
+                if (ok && s->rhs.kind == Rhs::Op)
+                    for (const Primary &a : s->rhs.args) ok = ok && pair_uniform_operand(a);
+                // a plain copy of an invariant scalar stays a broadcast (nothing to gain); ops on uniform values do not
+                if (ok && s->rhs.kind == Rhs::Prim && !(s->rhs.prim.kind == Primary::Val && pair_uniform.count(s->rhs.prim.value))) ok = false;
+                // truth values stay pairs of bools built from the (broadcast) uniform operands: the compiler evaluates such a
+                // comparison on the scalar unit anyway, and keeps the pair in lane masks only in that form (checked in the ISA)
+                if (ok && pair_bools.count(s->lhs)) ok = false;
+                if (ok) pair_uniform.insert(s->lhs);
+            } else if (s->kind == Stmt::If) {
+                pair_mark_uniform(s->then_);
+                pair_mark_uniform(s->else_);
+            }
+        }
+    }
+    // the phis of `w` that are uniform induction variables; marks them and what follows from them
+    std::vector<const Stmt *> pair_find_uniform_ivs(const Stmt *w) {
+        std::vector<const Stmt *> ivs;
+        if (getenv("MMHIP_PAIR_NO_UNIFORM")) return ivs;
+        for (const Stmt *ph : w->phis) {
+            if (!ph->in_pixel || ph->rhs.kind != Rhs::Prim || ph->rhs2.kind != Rhs::Prim) continue;
+            if (!pair_scalar_ty(ph->lhs->var->type) || pair_bools.count(ph->lhs)) continue;
+            if (!pair_invariant_scalar(ph->rhs.prim) || ph->rhs2.prim.kind != Primary::Val) continue;
+            const Stmt *d = ph->rhs2.prim.value->def;
+            if (!d || d->kind != Stmt::Assign || d->parent != w || d->rhs.kind != Rhs::Op || d->rhs.args.size() != 2) continue;
+            const char *cn = d->rhs.op->cname;
+            const Primary &a0 = d->rhs.args[0], &a1 = d->rhs.args[1];
+            const bool self0 = a0.kind == Primary::Val && a0.value == ph->lhs, self1 = a1.kind == Primary::Val && a1.value == ph->lhs;
+            const bool step = (!strcmp(cn, "ADD") && ((self0 && pair_invariant_scalar(a1)) || (self1 && pair_invariant_scalar(a0)))) ||
+                              (!strcmp(cn, "SUB") && self0 && pair_invariant_scalar(a1));
+            if (!step) continue;
+            ivs.push_back(ph);
+            pair_uniform.insert(ph->lhs);
+        }
+        if (!ivs.empty()) pair_mark_uniform(w->body);
+        return ivs;
+    }
+
     // `mask`: the expression (mm_bb) under which the block runs
     void pair_stmts(Block &b, const std::string &ind, const std::string &mask) {
         for (Stmt *s : b) {
             if (!s->in_pixel) continue;
             switch (s->kind) {
                 case Stmt::Assign:
+                    if (pair_uniform.count(s->lhs)) {       // scalar statement, the scalar kernel's own expression
+                        const char *ty = pair_bools.count(s->lhs) ? "bool" : s->lhs->var->type == Ty::Float ? "float" : "int";
+                        out << ind << "const " << ty << " u" << vname(s->lhs) << " = " << rhs(s->rhs, PIXEL, s, s->lhs->var) << ";\n";
+                        break;
+                    }
                     out << ind << vname(s->lhs) << " = " << prhs(s->rhs, s->lhs) << ";\n";
                     break;
                 case Stmt::If: {
@@ -706,6 +774,14 @@ struct Generator {
                     if (s->cond.prim.kind == Primary::Val) outside.insert(s->cond.prim.value);
                     for (Stmt *ph : s->phis)
                         if (ph->in_pixel) out << ind << vname(ph->lhs) << " = " << pval_as(ph->rhs.prim, ph->lhs) << ";\n";
+                    // uniform induction variables: a scalar twin, read inside the loop instead of the pair
+                    const std::vector<const Stmt *> ivs = pair_find_uniform_ivs(s);
+                    for (const Stmt *ph : ivs) {
+                        pair_uniform.erase(ph->lhs);       // the initial value is printed with the ordinary names
+                        const std::string init = prim(ph->rhs.prim, PIXEL);
+                        pair_uniform.insert(ph->lhs);
+                        out << ind << (ph->lhs->var->type == Ty::Float ? "float u" : "int u") << vname(ph->lhs) << " = " << init << ";\n";
+                    }
                     out << ind << "mm_bb " << a << " = mm_andb(" << mask << ", " << pbool(s->cond.prim) << ");\n";
                     out << ind << "while (" << a << ".x | " << a << ".y) {\n";
                     pair_stmts(s->body, ind + "  ", a);
@@ -722,8 +798,11 @@ struct Generator {
                     k = 0;
                     for (Stmt *ph : s->phis)
                         if (ph->in_pixel) out << ind << "  " << vname(ph->lhs) << " = " << a << "_n" << k++ << ";\n";
+                    for (const Stmt *ph : ivs) out << ind << "  u" << vname(ph->lhs) << " = " << prim(ph->rhs2.prim, PIXEL) << ";\n";
                     out << ind << "  " << a << " = mm_andb(" << a << ", " << pbool(s->cond.prim) << ");\n";
                     out << ind << "}\n";
+                    // after the loop a phi is read through its per-pixel copy (frozen at the pixel's own exit)
+                    for (const Stmt *ph : ivs) pair_uniform.erase(ph->lhs);
                     break;
                 }
                 default: break;

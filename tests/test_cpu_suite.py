@@ -431,6 +431,26 @@ def test_fastmath_sin_cos_equal_glibc_sampled():
     assert rep["checked"] > 25_000_000 and rep["exp_checked"] > 20_000_000 and rep["log_checked"] > 20_000_000
 
 
+def test_glibc_float_functions_equal_host_libm_sampled():
+    """mm_glibcf.h (glibc 2.35's float libm and float-complex functions restated; the text the JIT prelude
+    embeds for the complex ops) against the host's libm, bit for bit: every 1021st float for the
+    one-argument functions, the grid of special values and 400 000 random pairs per thread for atan2f,
+    hypotf and the complex functions.  The exhaustive run (every float; 480 M pairs per function; 0
+    mismatches) is recorded in profiles/r02_verify_glibcf.json; tools/verify_glibcf.c is the checker."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_build", "verify_glibcf")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-pthread", os.path.join(ROOT, "tools", "verify_glibcf.c"),
+                    "-o", exe, "-lm"], check=True)
+    r = subprocess.run([exe, "1021", "400000"], stdout=subprocess.PIPE, text=True)
+    rep = json.loads(r.stdout)
+    assert r.returncode == 0 and rep["total_mismatches"] == 0, {k: v for k, v in rep["functions"].items() if v["mismatches"]}
+    for name in ("expf", "logf", "sinf(sincosf)", "cosf(sincosf)", "atanf", "log1pf", "expm1f", "sinhf", "coshf"):
+        assert rep["functions"][name]["checked"] > 4_000_000
+    for name in ("atan2f", "hypotf", "cexpf", "clogf", "cpowf(c, z)", "csqrtf", "csinf", "ccosf", "ctanf", "csinhf", "ccoshf", "ctanhf"):
+        assert rep["functions"][name]["checked"] > 3_000_000
+
+
 def test_sqrt_less_power_of_two_identity():
     """sqrt_rn(a) < K  <=>  0 <= a < K*K for K a power of two, checked on every float in a
     window of +-2^16 ulps around K*K and on random floats."""
