@@ -106,7 +106,6 @@ struct Generator {
                     }
                 }
                 if (pair_uniform.count(v)) return "u" + vname(v);      // pair mode: wave-uniform loop value kept as a scalar
-                if (!pair_comp.empty() && pair_defs.count(v)) return vname(v) + pair_comp;   // one pixel of a pair
                 return vname(v);
             }
             case Primary::IntConst: return p.i < 0 ? "(" + std::to_string(p.i) + ")" : std::to_string(p.i);
@@ -432,32 +431,11 @@ struct Generator {
     bool pair_mode = false;
     std::set<const Value *> pair_defs;     // values defined in the pixel slice (vectors in pair mode)
     int pair_ids = 0;
-    // Generic pair mode (MMHIP_PAIR_GENERIC=1, or a body the arithmetic-only form does not cover when forced):
-    // any pure statement is evaluated per pixel by printing the scalar kernel's own expression twice, once
-    // with every pair-valued operand read through `.x` and once through `.y` (pair_comp), so image fetches,
-    // libm / complex calls, tuples and colours ride along; int / float / truth values keep their dedicated
-    // pair types and operators.  Conditionals whose blocks are more than a few cheap statements are entered
-    // when either pixel takes them (a real branch, mostly wave-uniform) instead of being if-converted.
-    std::string pair_comp;
-    bool pair_generic = false;
 
     static bool pair_scalar_ty(Ty t) { return t == Ty::Int || t == Ty::Float; }
     bool pair_prim_ok(const Primary &p) const {
         if (p.kind == Primary::IntConst || p.kind == Primary::FloatConst) return true;
         return p.kind == Primary::Val && pair_scalar_ty(p.value->var->type);
-    }
-    // statements the generic form can evaluate per component: anything pure that is not pixel-position magic
-    bool pair_generic_rhs_ok(const Rhs &r) const {
-        if (r.kind == Rhs::Internal) return r.internal != "__colF" && r.internal != "__rowF";
-        if (r.kind == Rhs::FilterCall) return false;
-        if (r.kind == Rhs::Closure) return r.filter->kind == Filter::MathMap;     // native calls live in the prologue
-        if (r.kind == Rhs::Op) {
-            if (!r.op->pure) return false;
-            for (const char *bad : {"RENDER", "OUTPUT_TUPLE", "START_DEBUG_TUPLE", "SET_DEBUG_TUPLE_DATA", "TREE_VECTOR_NTH",
-                                    "SET_TREE_VECTOR_NTH", "SOLVE_POLY_2", "SOLVE_POLY_3"})
-                if (!strcmp(r.op->cname, bad)) return false;
-        }
-        return true;
     }
     bool pair_rhs_ok(const Rhs &r) const {
         if (r.kind == Rhs::Prim) return pair_prim_ok(r.prim);
@@ -477,7 +455,6 @@ struct Generator {
             if (!s->in_pixel) continue;
             switch (s->kind) {
                 case Stmt::Assign:
-                    if (pair_generic && s->lhs && pair_generic_rhs_ok(s->rhs)) break;
                     if (!s->lhs || !pair_scalar_ty(s->lhs->var->type) || !pair_rhs_ok(s->rhs)) {
                         if (getenv("MMHIP_PAIR_DEBUG"))
                             fprintf(stderr, "pair mode: statement not covered (%s)\n",
@@ -487,17 +464,11 @@ struct Generator {
                     break;
                 case Stmt::If:
                 case Stmt::While:
-                    if (pair_generic && s->cond.kind == Rhs::Op && pair_generic_rhs_ok(s->cond)) {
-                        // a comparison folded into the condition: evaluated per component (pcond)
-                    } else if (s->cond.kind != Rhs::Prim || !pair_prim_ok(s->cond.prim) || s->cond.prim.type() != Ty::Int) {
-                        if (getenv("MMHIP_PAIR_DEBUG")) fprintf(stderr, "pair mode: condition not covered (kind %d)\n", (int)s->cond.kind);
-                        return false;
-                    }
+                    if (s->cond.kind != Rhs::Prim || !pair_prim_ok(s->cond.prim) || s->cond.prim.type() != Ty::Int) return false;
                     for (const Stmt *ph : s->phis) {
                         if (!ph->in_pixel) continue;
-                        if (ph->rhs.kind != Rhs::Prim || ph->rhs2.kind != Rhs::Prim) return false;
-                        if (pair_generic) continue;
-                        if (!pair_scalar_ty(ph->lhs->var->type) || !pair_prim_ok(ph->rhs.prim) || !pair_prim_ok(ph->rhs2.prim))
+                        if (!pair_scalar_ty(ph->lhs->var->type) || ph->rhs.kind != Rhs::Prim || ph->rhs2.kind != Rhs::Prim ||
+                            !pair_prim_ok(ph->rhs.prim) || !pair_prim_ok(ph->rhs2.prim))
                             return false;
                     }
                     if (s->kind == Stmt::If ? !(pair_block_ok(s->then_) && pair_block_ok(s->else_)) : !pair_block_ok(s->body)) return false;
@@ -507,18 +478,15 @@ struct Generator {
         }
         return true;
     }
-    bool pair_eligible() {
+    bool pair_eligible() const {
         if (!opt.fast_math_exact || !ks.natives.empty()) return false;
         const char *force = getenv("MMHIP_PAIR");          // 0: never, 1: whenever the body is covered, unset: small bodies
         if (force && !atoi(force)) return false;
         int stmts = 0, fetches = 0;
         pixel_stats(code.body, stmts, fetches);
-        const char *gen = getenv("MMHIP_PAIR_GENERIC");
-        pair_generic = gen && atoi(gen) != 0;
         // measured at 8192^2: Mandelbrot with its parameters baked in (24 statements) 0.372 -> 0.355 ms, the generic
         // quaternion form (57 statements, four loop-carried components to keep per pixel) 0.75 -> 0.86 ms
-        if (!pair_generic && (fetches || stmts < 4 || stmts > (force ? 400 : 40))) return false;
-        if (pair_generic && (stmts < 4 || stmts > 4000)) return false;
+        if (fetches || stmts < 4 || stmts > (force ? 400 : 40)) return false;
         const bool dbg = getenv("MMHIP_PAIR_DEBUG") != nullptr;
         for (int i = 0; i < 4; ++i)
             if (!code.result[i] || !pair_scalar_ty(code.result[i]->var->type)) {
@@ -629,34 +597,9 @@ struct Generator {
         for (const Primary &a : r.args) if (a.type() == Ty::Float) return Ty::Float;
         return Ty::Int;
     }
-    std::string pair_type(const Value *v) const {
-        if (pair_bools.count(v)) return "mm_bb";
-        if (v->var->type == Ty::Float) return "mm_pf";
-        if (v->var->type == Ty::Int) return "mm_pi";
-        return "mm_pair<" + ctype(v->var) + ">";
-    }
-    // the scalar kernel's expression for one pixel of the pair
-    std::string pair_component_rhs(const Rhs &r, const Stmt *stmt, const Value *lhs, const char *comp) {
-        pair_comp = comp;
-        std::string e = rhs(r, PIXEL, stmt, lhs->var);
-        pair_comp.clear();
-        if (pair_bools.count(lhs)) return "(bool)(" + e + ")";
-        switch (lhs->var->type) {      // the assignment conversion of the scalar kernel (aggregate initialisers do not narrow)
-            case Ty::Float: return "(float)(" + e + ")";
-            case Ty::Int: case Ty::Curve: case Ty::Gradient: return "(int)(" + e + ")";
-            case Ty::Color: return "(color_t)(" + e + ")";
-            default: return e;
-        }
-    }
-    std::string prhs(const Rhs &r, const Value *lhs, const Stmt *stmt = nullptr) {
+    std::string prhs(const Rhs &r, const Value *lhs) {
         const Ty lhs_ty = lhs->var->type;
         const bool as_bool = pair_bools.count(lhs) > 0;
-        if (pair_generic && r.kind == Rhs::Internal && r.internal != "x" && r.internal != "y") {     // t, R, frame, W ...: the same for both
-            const std::string e = lhs_ty == Ty::Float ? "(float)" + r.internal : "(int)" + r.internal;
-            return pair_type(lhs) + "{" + e + ", " + e + "}";
-        }
-        if (pair_generic && !(pair_scalar_ty(lhs_ty) && pair_rhs_ok(r)))
-            return pair_type(lhs) + "{" + pair_component_rhs(r, stmt, lhs, ".x") + ", " + pair_component_rhs(r, stmt, lhs, ".y") + "}";
         if (r.kind == Rhs::Prim) return as_bool ? pbool(r.prim) : pprim(r.prim, lhs_ty);
         if (r.kind == Rhs::Internal) return r.internal == "x" ? "mm_vf(x)" : "mm_y2";
         const char *cn = r.op->cname;
@@ -734,15 +677,11 @@ struct Generator {
         std::set<Value *> seen;
         for (Value *v : defs) {
             if (v->index < 0 || !seen.insert(v).second) continue;
-            out << ind << pair_type(v) << " " << vname(v) << ";\n";
+            out << ind << (pair_bools.count(v) ? "mm_bb" : pair_ctype(v->var->type)) << " " << vname(v) << ";\n";
         }
     }
     std::string pval_as(const Primary &p, const Value *lhs) {      // operand in the representation of `lhs`
-        if (pair_bools.count(lhs)) return pbool(p);
-        if (pair_scalar_ty(lhs->var->type)) return pprim(p, lhs->var->type);
-        if (p.kind == Primary::Val && p.value->index >= 0 && pair_defs.count(p.value)) return vname(p.value);
-        const std::string e = prim(p, PIXEL);            // a literal, a frame constant or an uninitialised value: both pixels alike
-        return pair_type(lhs) + "{" + e + ", " + e + "}";
+        return pair_bools.count(lhs) ? pbool(p) : pprim(p, lhs->var->type);
     }
     // Wave-uniform values inside a pair-mode loop.  A loop phi that starts from a literal or a frame constant
     // and is stepped by one -- `n = n + 1`, the iteration counter of every escape-time filter -- holds the same
@@ -803,17 +742,6 @@ struct Generator {
         return ivs;
     }
 
-    // condition of an if / while as a pair of bools
-    std::string pcond(const Rhs &c, const Stmt *s) {
-        if (c.kind == Rhs::Prim) return pbool(c.prim);
-        pair_comp = ".x";
-        const std::string ex = rhs(c, PIXEL, s, nullptr);
-        pair_comp = ".y";
-        const std::string ey = rhs(c, PIXEL, s, nullptr);
-        pair_comp.clear();
-        return "mm_bb{(bool)(" + ex + "), (bool)(" + ey + ")}";
-    }
-
     // `mask`: the expression (mm_bb) under which the block runs
     void pair_stmts(Block &b, const std::string &ind, const std::string &mask) {
         for (Stmt *s : b) {
@@ -825,29 +753,13 @@ struct Generator {
                         out << ind << "const " << ty << " u" << vname(s->lhs) << " = " << rhs(s->rhs, PIXEL, s, s->lhs->var) << ";\n";
                         break;
                     }
-                    out << ind << vname(s->lhs) << " = " << prhs(s->rhs, s->lhs, s) << ";\n";
+                    out << ind << vname(s->lhs) << " = " << prhs(s->rhs, s->lhs) << ";\n";
                     break;
                 case Stmt::If: {
                     const std::string c = "mm_c" + std::to_string(pair_ids++);
-                    out << ind << "const mm_bb " << c << " = " << pcond(s->cond, s) << ";\n";
-                    // small arithmetic blocks are if-converted (both sides evaluated, the phis select); anything with a call,
-                    // a fetch, a loop or more than a handful of statements is entered only when one of the two pixels takes it
-                    auto heavy = [&](const Block &blk) {
-                        int n = 0, f = 0;
-                        pixel_stats(blk, n, f);
-                        if (!pair_generic) return false;
-                        if (f || n > 6) return true;
-                        for (const Stmt *t : blk)
-                            if (t->in_pixel && (t->kind == Stmt::While || (t->kind == Stmt::Assign && t->rhs.kind == Rhs::Op && !pair_rhs_ok(t->rhs)))) return true;
-                        return false;
-                    };
-                    const bool hb_then = heavy(s->then_), hb_else = heavy(s->else_);
-                    if (hb_then) out << ind << "if (" << c << ".x | " << c << ".y) {\n";
-                    pair_stmts(s->then_, hb_then ? ind + "  " : ind, "mm_andb(" + mask + ", " + c + ")");
-                    if (hb_then) out << ind << "}\n";
-                    if (hb_else) out << ind << "if (!" << c << ".x | !" << c << ".y) {\n";
-                    pair_stmts(s->else_, hb_else ? ind + "  " : ind, "mm_andb(" + mask + ", mm_notb(" + c + "))");
-                    if (hb_else) out << ind << "}\n";
+                    out << ind << "const mm_bb " << c << " = " << pbool(s->cond.prim) << ";\n";
+                    pair_stmts(s->then_, ind, "mm_andb(" + mask + ", " + c + ")");
+                    pair_stmts(s->else_, ind, "mm_andb(" + mask + ", mm_notb(" + c + "))");
                     for (Stmt *ph : s->phis)
                         if (ph->in_pixel)
                             out << ind << vname(ph->lhs) << " = mm_sel2(" << c << ", " << pval_as(ph->rhs.prim, ph->lhs) << ", "
@@ -859,8 +771,7 @@ struct Generator {
                     std::set<const Value *> outside;
                     pair_uses(code.body, s, outside);
                     for (int i = 0; i < 4; ++i) outside.insert(code.result[i]);
-                    if (s->cond.kind == Rhs::Prim && s->cond.prim.kind == Primary::Val) outside.insert(s->cond.prim.value);
-                    if (s->cond.kind != Rhs::Prim) for (const Primary &a2 : s->cond.args) if (a2.kind == Primary::Val) outside.insert(a2.value);
+                    if (s->cond.prim.kind == Primary::Val) outside.insert(s->cond.prim.value);
                     for (Stmt *ph : s->phis)
                         if (ph->in_pixel) out << ind << vname(ph->lhs) << " = " << pval_as(ph->rhs.prim, ph->lhs) << ";\n";
                     // uniform induction variables: a scalar twin, read inside the loop instead of the pair
@@ -871,7 +782,7 @@ struct Generator {
                         pair_uniform.insert(ph->lhs);
                         out << ind << (ph->lhs->var->type == Ty::Float ? "float u" : "int u") << vname(ph->lhs) << " = " << init << ";\n";
                     }
-                    out << ind << "mm_bb " << a << " = mm_andb(" << mask << ", " << pcond(s->cond, s) << ");\n";
+                    out << ind << "mm_bb " << a << " = mm_andb(" << mask << ", " << pbool(s->cond.prim) << ");\n";
                     out << ind << "while (" << a << ".x | " << a << ".y) {\n";
                     pair_stmts(s->body, ind + "  ", a);
                     // back edge: a parallel copy (temporaries first).  A phi that is read after the loop, and the
@@ -879,7 +790,7 @@ struct Generator {
                     int k = 0;
                     for (Stmt *ph : s->phis)
                         if (ph->in_pixel) {
-                            const std::string ty = pair_type(ph->lhs);
+                            const std::string ty = pair_bools.count(ph->lhs) ? "mm_bb" : pair_ctype(ph->lhs->var->type);
                             const std::string nv = pval_as(ph->rhs2.prim, ph->lhs);
                             out << ind << "  const " << ty << " " << a << "_n" << k++ << " = "
                                 << (outside.count(ph->lhs) ? "mm_sel2(" + a + ", " + nv + ", " + vname(ph->lhs) + ")" : nv) << ";\n";
@@ -888,7 +799,7 @@ struct Generator {
                     for (Stmt *ph : s->phis)
                         if (ph->in_pixel) out << ind << "  " << vname(ph->lhs) << " = " << a << "_n" << k++ << ";\n";
                     for (const Stmt *ph : ivs) out << ind << "  u" << vname(ph->lhs) << " = " << prim(ph->rhs2.prim, PIXEL) << ";\n";
-                    out << ind << "  " << a << " = mm_andb(" << a << ", " << pcond(s->cond, s) << ");\n";
+                    out << ind << "  " << a << " = mm_andb(" << a << ", " << pbool(s->cond.prim) << ");\n";
                     out << ind << "}\n";
                     // after the loop a phi is read through its per-pixel copy (frozen at the pixel's own exit)
                     for (const Stmt *ph : ivs) pair_uniform.erase(ph->lhs);
@@ -1175,24 +1086,6 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
             ks.single_pixel = stmts > 400 || transfer_order.size() > 24;
             if (const char *e = getenv("MMHIP_SINGLE_PIXEL")) ks.single_pixel = atoi(e) != 0;
         }
-        if (ks.single_pixel && pair_mode && pair_generic) {
-            // large body, generic pair mode: exactly one pair of vertically adjacent pixels per work-item, no pixel loop
-            // (a loop would keep every frame constant live across its back edge).  A.ppt is 2 (= MM_UNROLL) for this kernel.
-            out << "  const int rl_a = row0 + (int)(threadIdx.x / MM_TILE_W), rl_b = rl_a + 1;\n"
-                   "  if (rl_a >= A.num_rows) return;\n"
-                   "  const int row_a = rl_a, row_b = rl_b < A.num_rows ? rl_b : A.num_rows - 1;\n"
-                   "  const mm_pf mm_y2 = {A.ytab[row_a], A.ytab[row_b]};\n";
-            pair_decls(pix_defs, "  ");
-            pair_stmts(code.body, "  ", "mm_bb{true, true}");
-            out << "  mm_tup<4> mm_ra, mm_rb;\n";
-            for (int i = 0; i < 4; ++i) {
-                const std::string v = pprim(Primary::V(code.result[i]), Ty::Float);
-                out << "  mm_ra.v[" << i << "] = " << v << ".x; mm_rb.v[" << i << "] = " << v << ".y;\n";
-            }
-            out << "  mm_store_pixel(A, row_a, col, mm_ra);\n  mm_store_pixel(A, row_b, col, mm_rb);\n}\n";
-            finish_source();
-            return;
-        }
         if (ks.single_pixel) {
             ks.unroll = 1;
             out << "  const int rl = row0;   // A.ppt is 1 for this kernel (KernelSource::single_pixel)\n"
@@ -1278,7 +1171,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         std::vector<std::string> hot_conds;
         find_hot_fetches(code.body, hot_conds);
         out << "  int mm_p = 0;\n";
-        if (ks.unroll > 1 && !hot_conds.empty() && !pair_mode) {
+        if (ks.unroll > 1 && !hot_conds.empty()) {
             out << "  bool mm_hot = true;\n";
             for (const std::string &c : hot_conds) out << "  mm_hot = mm_hot && " << c << ";\n";
             out << "  if (mm_hot) {\n";

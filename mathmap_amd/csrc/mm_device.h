@@ -253,9 +253,6 @@ MM_DEV mm_bb mm_eq(mm_pi a, mm_pi b) { return mm_bb{a.x == b.x, a.y == b.y}; }
 MM_DEV mm_pf mm_sel2(mm_bb c, mm_pf a, mm_pf b) { return mm_pf{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
 MM_DEV mm_pi mm_sel2(mm_bb c, mm_pi a, mm_pi b) { return mm_pi{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
 MM_DEV mm_bb mm_sel2(mm_bb c, mm_bb a, mm_bb b) { return mm_bb{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
-// any other value type of a pair (complex, tuples, colours, images): generic pair mode (hipgen.cpp)
-template <class T> struct mm_pair { T x, y; };
-template <class T> MM_DEV mm_pair<T> mm_sel2(mm_bb c, mm_pair<T> a, mm_pair<T> b) { return mm_pair<T>{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
 MM_DEV mm_pf mm_sqrt2(mm_pf a) { return mm_pf{mm_sqrt_f32(a.x), mm_sqrt_f32(a.y)}; }
 
 // ---- complex (float _Complex) -----------------------------------------------------------
