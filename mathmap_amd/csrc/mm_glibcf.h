@@ -41,6 +41,17 @@
 #define MMQ_SQRTF(a) sqrtf((a))    /* float, correctly rounded */
 #endif
 
+#ifndef MMQ_UNLIKELY
+#define MMQ_UNLIKELY(c) __builtin_expect(!!(c), 0)
+#endif
+
+// Two forms of the hot functions.  mmq_ref_* is the restatement, branch for branch as glibc has it.  On a GPU
+// every `if` around a few instructions costs more than the instructions (exec-mask bookkeeping, hazard nops --
+// scalar instructions take issue slots like vector ones), so the functions the complex ops run per pixel have a
+// second form: the common case evaluated straight through with the SAME operations in the same order
+// (alternatives picked by selects, ranges merged where the arithmetic coincides), everything unusual
+// (NaN, infinities, zeros, huge / tiny arguments) behind one unlikely test that calls the reference form.
+// Both forms go through tools/verify_glibcf.c, so "same bits" is checked, not argued.
 typedef struct { float re, im; } mmq_cf;
 typedef struct { float s, c; } mmq_sc;
 
@@ -110,7 +121,7 @@ MMQ_TABLE double mmq_logf_tab[32] = {   /* {invc, logc} x 16, e_logf_data.c */
     0x1.b2036576afce6p-1, 0x1.526e57720db08p-3, 0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3,
     0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2, 0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2};
 
-MMQ_FN float mmq_logf(float x) {
+MMQ_FN float mmq_ref_logf(float x) {
     unsigned ix = mmq_asuint(x);
     if (ix == 0x3f800000u) return 0.0f;
     if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {      /* x < 0x1p-126 or inf or nan */
@@ -120,6 +131,26 @@ MMQ_FN float mmq_logf(float x) {
         ix = mmq_asuint(x * 0x1p23f);                          /* subnormal: normalise */
         ix -= 23u << 23;
     }
+    const unsigned tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15);
+    const int k = (int)tmp >> 23;
+    const unsigned iz = ix - (tmp & 0xff800000u);
+    const double invc = mmq_logf_tab[2 * i], logc = mmq_logf_tab[2 * i + 1];
+    const double z = (double)mmq_asfloat(iz);
+    const double r = MMQ_FMA(z, invc, -1.0);
+    const double y0 = MMQ_FMA((double)k, 0x1.62e42fefa39efp-1, logc);
+    const double r2 = r * r;
+    double y = MMQ_FMA(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = MMQ_FMA(-0x1.00ea348b88334p-2, r2, y);
+    y = MMQ_FMA(y, r2, y0 + r);
+    return (float)y;
+}
+
+MMQ_FN float mmq_logf(float x) {
+    const unsigned ix = mmq_asuint(x);
+    // zero, negative, subnormal, inf, nan -> reference form.  (x == 1 needs no case of its own: its table entry is
+    // invc = 1, logc = 0, which makes r, y0 and the result +0.)
+    if (MMQ_UNLIKELY(ix - 0x00800000u >= 0x7f800000u - 0x00800000u)) return mmq_ref_logf(x);
     const unsigned tmp = ix - 0x3f330000u;
     const int i = (int)((tmp >> 19) & 15);
     const int k = (int)tmp >> 23;
@@ -161,7 +192,7 @@ MMQ_FN mmq_sc mmq_sincosf_poly(double x, double x2, int neg, int n) {
     return r;
 }
 
-MMQ_FN mmq_sc mmq_sincosf(float y) {
+MMQ_FN mmq_sc mmq_ref_sincosf(float y) {
     const unsigned top = (mmq_asuint(y) >> 20) & 0x7ff;
     double x = (double)y;
     mmq_sc r;
@@ -200,8 +231,23 @@ MMQ_FN mmq_sc mmq_sincosf(float y) {
     return r;
 }
 
+MMQ_FN mmq_sc mmq_sincosf(float y) {
+    const unsigned top = (mmq_asuint(y) >> 20) & 0x7ff;
+    if (MMQ_UNLIKELY(top >= 0x42f)) return mmq_ref_sincosf(y);       // |y| >= 120, inf, nan
+    // |y| < 120: reduce_fast.  Below pi/4 it yields n = 0 and x unchanged (fma(-0, hpi, x) = x), i.e. exactly the
+    // reference's direct polynomial; below 2^-12 the polynomial's value rounds to (y, 1) like the reference's shortcut.
+    double x = (double)y;
+    const double rr = x * 0x1.45f306dc9c883p+23;
+    const int n = ((int)rr + 0x800000) >> 24;
+    x = MMQ_FMA(-(double)n, 0x1.921fb54442d18p+0, x);
+    const double s = ((n + 1) & 2) ? -1.0 : 1.0;                     // quadrants 1 and 2
+    mmq_sc r = mmq_sincosf_poly(x * s, x * x, (n & 2) != 0, n);
+    if (top < 0x398) { r.s = y; r.c = 1.0f; }                        // |y| < 2^-12 (keeps -0 and the subnormals bit for bit)
+    return r;
+}
+
 // ---- atanf (s_atanf.c), atan2f (e_atan2f.c) ---------------------------------------------
-MMQ_FN float mmq_atanf(float x) {
+MMQ_FN float mmq_ref_atanf(float x) {
     const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
     const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
     const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
@@ -235,13 +281,13 @@ MMQ_FN float mmq_atanf(float x) {
     return hx < 0 ? -r : r;
 }
 
-MMQ_FN float mmq_atan2f(float y, float x) {
+MMQ_FN float mmq_ref_atan2f(float y, float x) {
     const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
                 pi_lo = -8.7422776573e-08f;
     const int hx = (int)mmq_asuint(x), hy = (int)mmq_asuint(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     float z;
     if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
-    if (hx == 0x3f800000) return mmq_atanf(y);
+    if (hx == 0x3f800000) return mmq_ref_atanf(y);
     const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
     if (iy == 0) {
         switch (m) {
@@ -272,13 +318,55 @@ MMQ_FN float mmq_atan2f(float y, float x) {
     const int k = (iy - ix) >> 23;
     if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
     else if (hx < 0 && k < -60) z = 0.0f;
-    else z = mmq_atanf(mmq_fabsf(y / x));
+    else z = mmq_ref_atanf(mmq_fabsf(y / x));
     switch (m) {
         case 0: return z;
         case 1: return mmq_asfloat(mmq_asuint(z) ^ 0x80000000u);
         case 2: return pi - (z - pi_lo);
         default: return (z - pi_lo) - pi;
     }
+}
+
+// atanf without branches: the five ranges differ in how the argument is reduced -- a quotient num / den (x / 1 for
+// the first range: exact) -- and in the constants added back; both are picked by selects, one division is made.
+MMQ_FN float mmq_atanf(float x) {
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const int hx = (int)mmq_asuint(x), ix = hx & 0x7fffffff;
+    const float ax = mmq_fabsf(x);
+    const int r0 = ix < 0x3ee00000, r1 = ix < 0x3f300000, r2 = ix < 0x3f980000, r3 = ix < 0x401c0000;
+    const float num = r0 ? x : r1 ? 2.0f * ax - 1.0f : r2 ? ax - 1.0f : r3 ? ax - 1.5f : -1.0f;
+    const float den = r0 ? 1.0f : r1 ? 2.0f + ax : r2 ? ax + 1.0f : r3 ? 1.0f + 1.5f * ax : ax;
+    const float hi = r1 ? 4.6364760399e-01f : r2 ? 7.8539812565e-01f : r3 ? 9.8279368877e-01f : 1.5707962513e+00f;
+    const float lo = r1 ? 5.0121582440e-09f : r2 ? 3.7748947079e-08f : r3 ? 3.4473217170e-08f : 7.5497894159e-08f;
+    const float xr = num / den;
+    const float z = xr * xr, w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float small = xr - xr * (s1 + s2);                          /* |x| < 0.4375 (and < 2^-29, where it is x) */
+    const float big = hi - ((xr * (s1 + s2) - lo) - xr);
+    float r = r0 ? small : (hx < 0 ? -big : big);
+    if (ix >= 0x4c000000) {                                           /* |x| >= 2^25, inf, nan: constants */
+        const float lim = 1.5707962513e+00f + 7.5497894159e-08f;
+        r = ix > 0x7f800000 ? x + x : (hx > 0 ? lim : -1.5707962513e+00f - 7.5497894159e-08f);
+    }
+    return r;
+}
+
+MMQ_FN float mmq_atan2f(float y, float x) {
+    const float pi = 3.1415927410e+00f, pi_o_2 = 1.5707963705e+00f, pi_lo = -8.7422776573e-08f;
+    const int hx = (int)mmq_asuint(x), hy = (int)mmq_asuint(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    // zeros, infinities and NaNs: the reference form.  (x == 1 is not special here: atanf is odd in this
+    // implementation, so atanf(y) equals the general path's +-atanf(|y / 1|).)
+    if (MMQ_UNLIKELY(ix - 1u >= 0x7f7fffffu || iy - 1u >= 0x7f7fffffu)) return mmq_ref_atan2f(y, x);
+    const int k = (iy - ix) >> 23;
+    float z = mmq_atanf(mmq_fabsf(y / x));
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    const float t = z - pi_lo;
+    const float neg = mmq_asfloat(mmq_asuint(z) ^ 0x80000000u);
+    return hx >= 0 ? (hy >= 0 ? z : neg) : (hy >= 0 ? pi - t : t - pi);
 }
 
 // ---- hypotf (e_hypotf.c, 2.35), x2y2m1f, scalbnf ---------------------------------------------
@@ -362,7 +450,7 @@ MMQ_FN float mmq_log1pf(float x) {
 MMQ_FN mmq_cf mmq_cmake(float re, float im) { mmq_cf c; c.re = re; c.im = im; return c; }
 
 // fpclassify-based tests of the templates: "finite" = FP_ZERO / FP_SUBNORMAL / FP_NORMAL
-MMQ_FN mmq_cf mmq_cexpf(mmq_cf x) {
+MMQ_FN mmq_cf mmq_ref_cexpf(mmq_cf x) {
     mmq_cf r;
     const int rfin = mmq_isfinitef(x.re), ifin = mmq_isfinitef(x.im);
     if (rfin) {
@@ -411,7 +499,7 @@ MMQ_FN mmq_cf mmq_cexpf(mmq_cf x) {
     return r;
 }
 
-MMQ_FN mmq_cf mmq_clogf(mmq_cf x) {
+MMQ_FN mmq_cf mmq_ref_clogf(mmq_cf x) {
     mmq_cf r;
     const int rnan = mmq_isnanf(x.re), inan = mmq_isnanf(x.im);
     if (x.re == 0.0f && x.im == 0.0f) {
@@ -454,6 +542,45 @@ MMQ_FN mmq_cf mmq_clogf(mmq_cf x) {
     }
     r.im = mmq_nanf();
     r.re = (mmq_isinff(x.re) || mmq_isinff(x.im)) ? mmq_inff() : mmq_nanf();
+    return r;
+}
+
+MMQ_FN mmq_cf mmq_cexpf(mmq_cf x) {
+    // both parts finite and the real part <= 88: sincos, exp, two products.  Everything else (overflow staging,
+    // infinities, NaN) is the reference form.
+    if (MMQ_UNLIKELY(!mmq_isfinitef(x.re) || !mmq_isfinitef(x.im) || x.re > 88.0f)) return mmq_ref_cexpf(x);
+    mmq_sc sc = mmq_sincosf(x.im);
+    if (!(mmq_fabsf(x.im) > MMQ_FLT_MIN)) { sc.s = x.im; sc.c = 1.0f; }
+    const float exp_val = mmq_expf(x.re);
+    mmq_cf r;
+    r.re = exp_val * sc.c;
+    r.im = exp_val * sc.s;
+    return r;
+}
+
+MMQ_FN mmq_cf mmq_clogf(mmq_cf x) {
+    float absx = mmq_fabsf(x.re), absy = mmq_fabsf(x.im);
+    if (absx < absy) { const float t = absx; absx = absy; absy = t; }
+    // NaN, both zero, or a modulus that the reference rescales (huge, or both parts subnormal): reference form
+    if (MMQ_UNLIKELY(!(absx <= MMQ_FLT_MAX / 2.0f) || !(absy == absy) || absx < MMQ_FLT_MIN)) return mmq_ref_clogf(x);
+    mmq_cf r;
+    // scale == 0 from here.  Near |z| = 1 the reference goes through log1pf of |z|^2 - 1, formed in one of four ways
+    const int c1 = absx == 1.0f;
+    const int c2 = absx > 1.0f && absx < 2.0f && absy < 1.0f;
+    const int c34 = absx < 1.0f && absx >= 0.5f;
+    const int c3 = c34 && absy < MMQ_FLT_EPSILON / 2.0f;
+    const int c4 = c34 && absx * absx + absy * absy >= 0.5f;
+    if (c1 | c2 | c3 | c4) {
+        const float y2 = absy * absy;
+        const float t = (absx - 1.0f) * (absx + 1.0f);
+        const float t2 = absy >= MMQ_FLT_EPSILON ? t + y2 : t;
+        const float d2m1 = c1 ? y2 : c2 ? t2 : c3 ? t : mmq_x2y2m1f(absx, absy);
+        r.re = mmq_log1pf(d2m1) / 2.0f;
+    } else {
+        const float d = mmq_hypotf(absx, absy);
+        r.re = mmq_logf(d);                       /* (scale is 0: the reference subtracts 0 * ln2) */
+    }
+    r.im = mmq_atan2f(x.im, x.re);
     return r;
 }
 
