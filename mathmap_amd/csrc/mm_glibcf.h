@@ -344,7 +344,7 @@ MMQ_FN float mmq_atanf(float x) {
     const float z = xr * xr, w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    const float small = xr - xr * (s1 + s2);                          /* |x| < 0.4375 (and < 2^-29, where it is x) */
+    const float small = ix < 0x31000000 ? x : xr - xr * (s1 + s2);    /* |x| < 0.4375; below 2^-29 the reference returns x (keeps -0) */
     const float big = hi - ((xr * (s1 + s2) - lo) - xr);
     float r = r0 ? small : (hx < 0 ? -big : big);
     if (ix >= 0x4c000000) {                                           /* |x| >= 2^25, inf, nan: constants */
