@@ -257,9 +257,8 @@ MM_DEV mm_pf mm_sqrt2(mm_pf a) { return mm_pf{mm_sqrt_f32(a.x), mm_sqrt_f32(a.y)
 
 // ---- complex (float _Complex) -----------------------------------------------------------
 // In the generated C, complex values only flow COMPLEX() -> c*f() -> crealf/cimagf
-// (builtins.lisp:679-941).  csqrtf cexpf clogf cpowf cargf and the six trigonometric / hyperbolic
-// functions run glibc's own float algorithms (mm_glibcf.h); the inverse functions and cgamma still
-// compute in double and round once (<= 1-2 float ulps from glibc's).
+// (builtins.lisp:679-941).  All sixteen libm functions of that list run glibc's own float algorithms
+// (mm_glibcf.h); cgamma restates the reference's own builtins/spec_func.c below.
 MM_DEV mm_complex mm_cmake(float r, float i) { mm_complex c; c.re = r; c.im = i; return c; }
 // opmacros.h:63: COMPLEX(r, i) = (r) + (i) * I.  C's I is the complex value (0, 1), so gcc evaluates the real part
 // as r + i * 0.0f: NaN for an infinite or NaN imaginary part, and -0 + (+0) = +0 for r = -0 with i >= +0 -- both
@@ -314,38 +313,12 @@ MM_DEV mm_complex ctanf(mm_complex z) { return mm_from_q(mmq_ctanf(mm_to_q(z)));
 MM_DEV mm_complex csinhf(mm_complex z) { return mm_from_q(mmq_csinhf(mm_to_q(z))); }
 MM_DEV mm_complex ccoshf(mm_complex z) { return mm_from_q(mmq_ccoshf(mm_to_q(z))); }
 MM_DEV mm_complex ctanhf(mm_complex z) { return mm_from_q(mmq_ctanhf(mm_to_q(z))); }
-MM_DEV mm_dc mm_dcasinh(mm_dc z) {
-    mm_dc one = mm_dcmake(1.0, 0.0);
-    // fold into the right half plane for accuracy, asinh is odd
-    bool neg = z.re < 0.0 || (z.re == 0.0 && signbit(z.re));
-    mm_dc w = neg ? mm_dcmake(-z.re, -z.im) : z;
-    mm_dc r = mm_dclog(mm_dcadd(w, mm_dcsqrt(mm_dcadd(mm_dcmul(w, w), one))));
-    return neg ? mm_dcmake(-r.re, -r.im) : r;
-}
-MM_DEV mm_complex casinhf(mm_complex z) { return mm_narrow(mm_dcasinh(mm_widen(z))); }
-MM_DEV mm_complex casinf(mm_complex z) {   // casin(z) = -i casinh(i z)
-    mm_dc r = mm_dcasinh(mm_dcmake(-(double)z.im, (double)z.re));
-    return mm_cmake((float)r.im, (float)-r.re);
-}
-MM_DEV mm_complex cacosf(mm_complex z) {   // pi/2 - casin(z)
-    mm_dc r = mm_dcasinh(mm_dcmake(-(double)z.im, (double)z.re));
-    return mm_cmake((float)(1.5707963267948966 - r.im), (float)r.re);
-}
-MM_DEV mm_dc mm_dcatanh(mm_dc z) {   // 1/2 (log(1+z) - log(1-z))
-    mm_dc one = mm_dcmake(1.0, 0.0);
-    mm_dc a = mm_dclog(mm_dcadd(one, z)), b = mm_dclog(mm_dcsub(one, z));
-    return mm_dcmake(0.5 * (a.re - b.re), 0.5 * (a.im - b.im));
-}
-MM_DEV mm_complex catanhf(mm_complex z) { return mm_narrow(mm_dcatanh(mm_widen(z))); }
-MM_DEV mm_complex catanf(mm_complex z) {   // catan(z) = -i catanh(i z)
-    mm_dc r = mm_dcatanh(mm_dcmake(-(double)z.im, (double)z.re));
-    return mm_cmake((float)r.im, (float)-r.re);
-}
-MM_DEV mm_complex cacoshf(mm_complex z) {  // log(z + sqrt(z+1) sqrt(z-1))
-    mm_dc w = mm_widen(z), one = mm_dcmake(1.0, 0.0);
-    mm_dc r = mm_dclog(mm_dcadd(w, mm_dcmul(mm_dcsqrt(mm_dcadd(w, one)), mm_dcsqrt(mm_dcsub(w, one)))));
-    return mm_narrow(r);
-}
+MM_DEV mm_complex casinhf(mm_complex z) { return mm_from_q(mmq_casinhf(mm_to_q(z))); }
+MM_DEV mm_complex casinf(mm_complex z) { return mm_from_q(mmq_casinf(mm_to_q(z))); }
+MM_DEV mm_complex cacosf(mm_complex z) { return mm_from_q(mmq_cacosf(mm_to_q(z))); }
+MM_DEV mm_complex cacoshf(mm_complex z) { return mm_from_q(mmq_cacoshf(mm_to_q(z))); }
+MM_DEV mm_complex catanf(mm_complex z) { return mm_from_q(mmq_catanf(mm_to_q(z))); }
+MM_DEV mm_complex catanhf(mm_complex z) { return mm_from_q(mmq_catanhf(mm_to_q(z))); }
 // builtins/spec_func.c:35-64 (Luke's approximation; double-complex internally)
 MM_DEV mm_dc mm_dcpow(mm_dc a, mm_dc b) { return mm_dcexp(mm_dcmul(b, mm_dclog(a))); }
 MM_DEV mm_complex cgamma(mm_complex zf) {

@@ -13,7 +13,8 @@
 //   sysdeps/ieee754/flt-32/s_atanf.c, e_atan2f.c, s_log1pf.c, s_expm1f.c, e_sinhf.c, e_coshf.c,
 //   e_hypotf.c, x2y2m1f.c, s_scalbnf.c                                     (fdlibm, float)
 //   math/s_cexp_template.c, s_clog_template.c, s_cpow_template.c, s_csqrt_template.c,
-//   s_csin/ccos/ctan/csinh/ccosh/ctanh_template.c                          (complex templates)
+//   s_csin/ccos/ctan/csinh/ccosh/ctanh_template.c, k_casinh_template.c,
+//   s_casin/cacos/casinh/cacosh/catan/catanh_template.c                    (complex templates)
 //
 // x86-64 selects the FMA builds of expf, logf and sincosf at load time (ifunc: every CPU with
 // FMA + AVX2, i.e. this container and the GPU boxes' hosts); where those builds contract a
@@ -1050,6 +1051,300 @@ MMQ_FN mmq_cf mmq_ctanf(mmq_cf x) {
         res.re = sinrx * cosrx / den;
         res.im = sinhix * coshix / den;
     }
+    return res;
+}
+
+// ---- casinhf / casinf / cacosf / cacoshf (math/k_casinh_template.c, s_casinh/casin/cacos/cacosh_template.c),
+//      catanf / catanhf (s_catan_template.c, s_catanh_template.c) -----------------------------------------------
+#define MMQ_HAVE_BATCH3 1
+#define MMQ_PI_F 3.14159265358979323846f
+#define MMQ_PI_2_F 1.57079632679489661923f
+#define MMQ_PI_4_F 0.78539816339744830962f
+#define MMQ_LN2_F 0.69314718055994530942f
+
+MMQ_FN mmq_cf mmq_kernel_casinhf(mmq_cf x, int adj) {
+    mmq_cf res, y;
+    const float eps = MMQ_FLT_EPSILON;
+    const float rx = mmq_fabsf(x.re), ix = mmq_fabsf(x.im);
+    if (rx >= 1.0f / eps || ix >= 1.0f / eps) {
+        y.re = rx;
+        y.im = ix;
+        if (adj) { const float t = y.re; y.re = mmq_copysignf(y.im, x.im); y.im = t; }
+        res = mmq_clogf(y);
+        res.re += MMQ_LN2_F;
+    } else if (rx >= 0.5f && ix < eps / 8.0f) {
+        const float s = mmq_hypotf(1.0f, rx);
+        res.re = mmq_logf(rx + s);
+        res.im = adj ? mmq_atan2f(s, x.im) : mmq_atan2f(ix, s);
+    } else if (rx < eps / 8.0f && ix >= 1.5f) {
+        const float s = MMQ_SQRTF((ix + 1.0f) * (ix - 1.0f));
+        res.re = mmq_logf(ix + s);
+        res.im = adj ? mmq_atan2f(rx, mmq_copysignf(s, x.im)) : mmq_atan2f(s, rx);
+    } else if (ix > 1.0f && ix < 1.5f && rx < 0.5f) {
+        if (rx < eps * eps) {
+            const float ix2m1 = (ix + 1.0f) * (ix - 1.0f);
+            const float s = MMQ_SQRTF(ix2m1);
+            res.re = mmq_log1pf(2.0f * (ix2m1 + ix * s)) / 2.0f;
+            res.im = adj ? mmq_atan2f(rx, mmq_copysignf(s, x.im)) : mmq_atan2f(s, rx);
+        } else {
+            const float ix2m1 = (ix + 1.0f) * (ix - 1.0f);
+            const float rx2 = rx * rx;
+            const float f = rx2 * (2.0f + rx2 + 2.0f * ix * ix);
+            const float d = MMQ_SQRTF(ix2m1 * ix2m1 + f);
+            const float dp = d + ix2m1;
+            const float dm = f / dp;
+            const float r1 = MMQ_SQRTF((dm + rx2) / 2.0f);
+            const float r2 = rx * ix / r1;
+            res.re = mmq_log1pf(rx2 + dp + 2.0f * (rx * r1 + ix * r2)) / 2.0f;
+            res.im = adj ? mmq_atan2f(rx + r1, mmq_copysignf(ix + r2, x.im)) : mmq_atan2f(ix + r2, rx + r1);
+        }
+    } else if (ix == 1.0f && rx < 0.5f) {
+        if (rx < eps / 8.0f) {
+            res.re = mmq_log1pf(2.0f * (rx + MMQ_SQRTF(rx))) / 2.0f;
+            res.im = adj ? mmq_atan2f(MMQ_SQRTF(rx), mmq_copysignf(1.0f, x.im)) : mmq_atan2f(1.0f, MMQ_SQRTF(rx));
+        } else {
+            const float d = rx * MMQ_SQRTF(4.0f + rx * rx);
+            const float s1 = MMQ_SQRTF((d + rx * rx) / 2.0f);
+            const float s2 = MMQ_SQRTF((d - rx * rx) / 2.0f);
+            res.re = mmq_log1pf(rx * rx + d + 2.0f * (rx * s1 + s2)) / 2.0f;
+            res.im = adj ? mmq_atan2f(rx + s1, mmq_copysignf(1.0f + s2, x.im)) : mmq_atan2f(1.0f + s2, rx + s1);
+        }
+    } else if (ix < 1.0f && rx < 0.5f) {
+        if (ix >= eps) {
+            if (rx < eps * eps) {
+                const float onemix2 = (1.0f + ix) * (1.0f - ix);
+                const float s = MMQ_SQRTF(onemix2);
+                res.re = mmq_log1pf(2.0f * rx / s) / 2.0f;
+                res.im = adj ? mmq_atan2f(s, x.im) : mmq_atan2f(ix, s);
+            } else {
+                const float onemix2 = (1.0f + ix) * (1.0f - ix);
+                const float rx2 = rx * rx;
+                const float f = rx2 * (2.0f + rx2 + 2.0f * ix * ix);
+                const float d = MMQ_SQRTF(onemix2 * onemix2 + f);
+                const float dp = d + onemix2;
+                const float dm = f / dp;
+                const float r1 = MMQ_SQRTF((dp + rx2) / 2.0f);
+                const float r2 = rx * ix / r1;
+                res.re = mmq_log1pf(rx2 + dm + 2.0f * (rx * r1 + ix * r2)) / 2.0f;
+                res.im = adj ? mmq_atan2f(rx + r1, mmq_copysignf(ix + r2, x.im)) : mmq_atan2f(ix + r2, rx + r1);
+            }
+        } else {
+            const float s = mmq_hypotf(1.0f, rx);
+            res.re = mmq_log1pf(2.0f * rx * (rx + s)) / 2.0f;
+            res.im = adj ? mmq_atan2f(s, x.im) : mmq_atan2f(ix, s);
+        }
+    } else {
+        y.re = (rx - ix) * (rx + ix) + 1.0f;
+        y.im = 2.0f * rx * ix;
+        y = mmq_csqrtf(y);
+        y.re += rx;
+        y.im += ix;
+        if (adj) { const float t = y.re; y.re = mmq_copysignf(y.im, x.im); y.im = t; }
+        res = mmq_clogf(y);
+    }
+    res.re = mmq_copysignf(res.re, x.re);
+    res.im = mmq_copysignf(res.im, adj ? 1.0f : x.im);
+    return res;
+}
+
+MMQ_FN mmq_cf mmq_casinhf(mmq_cf x) {
+    mmq_cf res;
+    const int rnan = mmq_isnanf(x.re), inan = mmq_isnanf(x.im), rinf = mmq_isinff(x.re), iinf = mmq_isinff(x.im);
+    if (rnan || inan || rinf || iinf) {
+        if (iinf) {
+            res.re = mmq_copysignf(mmq_inff(), x.re);
+            if (rnan) res.im = mmq_nanf();
+            else res.im = mmq_copysignf(!rinf ? MMQ_PI_2_F : MMQ_PI_4_F, x.im);
+        } else if (rnan || rinf) {
+            res.re = x.re;
+            if ((rinf && !inan) || (rnan && x.im == 0.0f)) res.im = mmq_copysignf(0.0f, x.im);
+            else res.im = mmq_nanf();
+        } else {
+            res.re = mmq_nanf();
+            res.im = mmq_nanf();
+        }
+        return res;
+    }
+    if (x.re == 0.0f && x.im == 0.0f) return x;
+    return mmq_kernel_casinhf(x, 0);
+}
+
+MMQ_FN mmq_cf mmq_casinf(mmq_cf x) {
+    mmq_cf res;
+    if (mmq_isnanf(x.re) || mmq_isnanf(x.im)) {
+        if (x.re == 0.0f) return x;
+        if (mmq_isinff(x.re) || mmq_isinff(x.im)) { res.re = mmq_nanf(); res.im = mmq_copysignf(mmq_inff(), x.im); }
+        else { res.re = mmq_nanf(); res.im = mmq_nanf(); }
+        return res;
+    }
+    const mmq_cf y = mmq_casinhf(mmq_cmake(-x.im, x.re));
+    res.re = y.im;
+    res.im = -y.re;
+    return res;
+}
+
+MMQ_FN mmq_cf mmq_cacosf(mmq_cf x) {
+    mmq_cf y, res;
+    const int special = !mmq_isfinitef(x.re) || !mmq_isfinitef(x.im) || (x.re == 0.0f && x.im == 0.0f);
+    if (special) {
+        y = mmq_casinf(x);
+        res.re = MMQ_PI_2_F - y.re;
+        if (res.re == 0.0f) res.re = 0.0f;
+        res.im = -y.im;
+    } else {
+        y = mmq_kernel_casinhf(mmq_cmake(-x.im, x.re), 1);
+        res.re = y.im;
+        res.im = y.re;
+    }
+    return res;
+}
+
+MMQ_FN mmq_cf mmq_cacoshf(mmq_cf x) {
+    mmq_cf res;
+    const int rnan = mmq_isnanf(x.re), inan = mmq_isnanf(x.im), rinf = mmq_isinff(x.re), iinf = mmq_isinff(x.im);
+    if (rnan || inan || rinf || iinf) {
+        if (iinf) {
+            res.re = mmq_inff();
+            if (rnan) res.im = mmq_nanf();
+            else res.im = mmq_copysignf(rinf ? (x.re < 0.0f ? MMQ_PI_F - MMQ_PI_4_F : MMQ_PI_4_F) : MMQ_PI_2_F, x.im);
+        } else if (rinf) {
+            res.re = mmq_inff();
+            if (!inan) res.im = mmq_copysignf(mmq_signbitf(x.re) ? MMQ_PI_F : 0.0f, x.im);
+            else res.im = mmq_nanf();
+        } else {
+            res.re = mmq_nanf();
+            res.im = (x.re == 0.0f) ? MMQ_PI_2_F : mmq_nanf();
+        }
+        return res;
+    }
+    if (x.re == 0.0f && x.im == 0.0f) {
+        res.re = 0.0f;
+        res.im = mmq_copysignf(MMQ_PI_2_F, x.im);
+        return res;
+    }
+    const mmq_cf y = mmq_kernel_casinhf(mmq_cmake(-x.im, x.re), 1);
+    if (mmq_signbitf(x.im)) { res.re = y.re; res.im = -y.im; }
+    else { res.re = -y.re; res.im = y.im; }
+    return res;
+}
+
+// the denominator 1 - |z|^2 shared by catanf and catanhf (absx >= absy already ordered by the caller)
+MMQ_FN float mmq_catan_den(float absx, float absy) {
+    float den;
+    if (absy < MMQ_FLT_EPSILON / 2.0f) {
+        den = (1.0f - absx) * (1.0f + absx);
+        if (den == 0.0f) den = 0.0f;
+    } else if (absx >= 1.0f)
+        den = (1.0f - absx) * (1.0f + absx) - absy * absy;
+    else if (absx >= 0.75f || absy >= 0.5f)
+        den = -mmq_x2y2m1f(absx, absy);
+    else
+        den = (1.0f - absx) * (1.0f + absx) - absy * absy;
+    return den;
+}
+
+MMQ_FN mmq_cf mmq_catanf(mmq_cf x) {
+    mmq_cf res;
+    const int rnan = mmq_isnanf(x.re), inan = mmq_isnanf(x.im), rinf = mmq_isinff(x.re), iinf = mmq_isinff(x.im);
+    const float eps = MMQ_FLT_EPSILON;
+    if (rnan || inan || rinf || iinf) {
+        if (rinf) {
+            res.re = mmq_copysignf(MMQ_PI_2_F, x.re);
+            res.im = mmq_copysignf(0.0f, x.im);
+        } else if (iinf) {
+            res.re = !rnan ? mmq_copysignf(MMQ_PI_2_F, x.re) : mmq_nanf();
+            res.im = mmq_copysignf(0.0f, x.im);
+        } else if (x.im == 0.0f) {
+            res.re = mmq_nanf();
+            res.im = mmq_copysignf(0.0f, x.im);
+        } else {
+            res.re = mmq_nanf();
+            res.im = mmq_nanf();
+        }
+        return res;
+    }
+    if (x.re == 0.0f && x.im == 0.0f) return x;
+    if (mmq_fabsf(x.re) >= 16.0f / eps || mmq_fabsf(x.im) >= 16.0f / eps) {
+        res.re = mmq_copysignf(MMQ_PI_2_F, x.re);
+        if (mmq_fabsf(x.re) <= 1.0f) res.im = 1.0f / x.im;
+        else if (mmq_fabsf(x.im) <= 1.0f) res.im = x.im / x.re / x.re;
+        else {
+            const float h = mmq_hypotf(x.re / 2.0f, x.im / 2.0f);
+            res.im = x.im / h / h / 4.0f;
+        }
+        return res;
+    }
+    float absx = mmq_fabsf(x.re), absy = mmq_fabsf(x.im);
+    if (absx < absy) { const float t = absx; absx = absy; absy = t; }
+    float den = mmq_catan_den(absx, absy);
+    res.re = 0.5f * mmq_atan2f(2.0f * x.re, den);
+    if (mmq_fabsf(x.im) == 1.0f && mmq_fabsf(x.re) < eps * eps)
+        res.im = mmq_copysignf(0.5f, x.im) * (MMQ_LN2_F - mmq_logf(mmq_fabsf(x.re)));
+    else {
+        float r2 = 0.0f, num, f;
+        if (mmq_fabsf(x.re) >= eps * eps) r2 = x.re * x.re;
+        num = x.im + 1.0f;
+        num = r2 + num * num;
+        den = x.im - 1.0f;
+        den = r2 + den * den;
+        f = num / den;
+        if (f < 0.5f) res.im = 0.25f * mmq_logf(f);
+        else {
+            num = 4.0f * x.im;
+            res.im = 0.25f * mmq_log1pf(num / den);
+        }
+    }
+    return res;
+}
+
+MMQ_FN mmq_cf mmq_catanhf(mmq_cf x) {
+    mmq_cf res;
+    const int rnan = mmq_isnanf(x.re), inan = mmq_isnanf(x.im), rinf = mmq_isinff(x.re), iinf = mmq_isinff(x.im);
+    const float eps = MMQ_FLT_EPSILON;
+    if (rnan || inan || rinf || iinf) {
+        if (iinf) {
+            res.re = mmq_copysignf(0.0f, x.re);
+            res.im = mmq_copysignf(MMQ_PI_2_F, x.im);
+        } else if (rinf || x.re == 0.0f) {
+            res.re = mmq_copysignf(0.0f, x.re);
+            res.im = !inan ? mmq_copysignf(MMQ_PI_2_F, x.im) : mmq_nanf();
+        } else {
+            res.re = mmq_nanf();
+            res.im = mmq_nanf();
+        }
+        return res;
+    }
+    if (x.re == 0.0f && x.im == 0.0f) return x;
+    if (mmq_fabsf(x.re) >= 16.0f / eps || mmq_fabsf(x.im) >= 16.0f / eps) {
+        res.im = mmq_copysignf(MMQ_PI_2_F, x.im);
+        if (mmq_fabsf(x.im) <= 1.0f) res.re = 1.0f / x.re;
+        else if (mmq_fabsf(x.re) <= 1.0f) res.re = x.re / x.im / x.im;
+        else {
+            const float h = mmq_hypotf(x.re / 2.0f, x.im / 2.0f);
+            res.re = x.re / h / h / 4.0f;
+        }
+        return res;
+    }
+    if (mmq_fabsf(x.re) == 1.0f && mmq_fabsf(x.im) < eps * eps)
+        res.re = mmq_copysignf(0.5f, x.re) * (MMQ_LN2_F - mmq_logf(mmq_fabsf(x.im)));
+    else {
+        float i2 = 0.0f;
+        if (mmq_fabsf(x.im) >= eps * eps) i2 = x.im * x.im;
+        float num = 1.0f + x.re;
+        num = i2 + num * num;
+        float den = 1.0f - x.re;
+        den = i2 + den * den;
+        const float f = num / den;
+        if (f < 0.5f) res.re = 0.25f * mmq_logf(f);
+        else {
+            num = 4.0f * x.re;
+            res.re = 0.25f * mmq_log1pf(num / den);
+        }
+    }
+    float absx = mmq_fabsf(x.re), absy = mmq_fabsf(x.im);
+    if (absx < absy) { const float t = absx; absx = absy; absy = t; }
+    const float den2 = mmq_catan_den(absx, absy);
+    res.im = 0.5f * mmq_atan2f(2.0f * x.im, den2);
     return res;
 }
 
