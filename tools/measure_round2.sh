@@ -23,6 +23,6 @@ for w in $WL; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$w -o pm --output-format csv -- python3 bench.py $ARGS --no-extras --steps $PSTEPS --warmup 1 > $O/pmc_fetch_$w.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$w -o pm --output-format csv -- python3 bench.py $ARGS --no-extras --steps $PSTEPS --warmup 1 > $O/pmc_write_$w.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $O/pmc_sq_$w -o pm --output-format csv -- python3 bench.py $ARGS --no-extras --steps $PSTEPS --warmup 1 > $O/pmc_sq_$w.log 2>&1
-  if grep -qi "fault\|hang" $O/pmc_sq_$w.log; then echo "fault in $w"; exit 1; fi
+  if grep -qi "memory access fault\|gpu fault\|hsa_status_error" $O/pmc_sq_$w.log; then echo "fault in $w"; exit 1; fi
 done
 find $O -name "*.csv" | head -60
