@@ -175,7 +175,7 @@ def pmc_traffic(workload, size, kernel_key):
             continue
         best = (fn, j)
     if not best:
-        return None, {"file": None, "why": "no PMC summary committed for this workload / size"}
+        return None, {"file": None, "kernel_key_now": kernel_key, "why": "no PMC summary committed for this workload / size"}
     fn, j = best
     src = {"file": os.path.relpath(fn, ROOT), "collected_for_kernel_key": j.get("kernel_key"), "kernel_key_now": kernel_key,
            "collected_at_commit": j.get("commit")}

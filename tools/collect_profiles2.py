@@ -24,7 +24,7 @@ def counters(d, match):
             n = r["Kernel_Name"]
             if match not in n:
                 continue
-            short = n.split("(")[0].replace("mm::(anonymous namespace)::", "").replace("void ", "")
+            short = n.replace("mm::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
