@@ -96,13 +96,6 @@ class Filter:
         oracle prints): lowering output only."""
         return lib().mmhip_filter_ir_json_raw(self._h).decode()
 
-    @property
-    def needs_constants(self):
-        """True for a filter that only compiles once its scalar user values are literals
-        (recursion whose depth they control): it has no generic IR/kernel, every render
-        builds -- and caches -- the variant for the current values."""
-        return self.ir_json == ""
-
     def specialized(self, values=None):
         """The variant with every int/float/bool user value baked in: the declared defaults,
         overridden by `values` (name -> number).  What a render with those values runs."""

@@ -68,11 +68,17 @@ std::map<mmabi_input_drawable_t *, ModuleInfo *> g_drawable_owner;
 struct Importer {
     Module &mod;
     FilterCode &code;
-    std::map<mmabi_filter_t *, Filter *> filters;
+    // shared by the importers of one module: the main filter's code and the bodies of the filters it calls
+    struct Shared {
+        std::map<mmabi_filter_t *, Filter *> filters;
+        std::vector<mmabi_filter_t *> called;      // callees of RHS_FILTER statements, in first-seen order
+    };
+    Shared &shared;
+    std::map<mmabi_filter_t *, Filter *> &filters;
     std::map<mmabi_compvar_t *, CompVar *> vars;
     std::map<mmabi_value_t *, Value *> vals;
 
-    Importer(Module &m, FilterCode &c) : mod(m), code(c) {}
+    Importer(Module &m, FilterCode &c, Shared &sh) : mod(m), code(c), shared(sh), filters(sh.filters) {}
 
     static unsigned flags_of(mmabi_filter_t *f) {   // mathmap_common.c:59-72
         bool pixel = false, stretched = false;
@@ -187,10 +193,22 @@ struct Importer {
                 out.kind = Rhs::Tuple;
                 for (int i = 0; i < r->v.tuple.length; ++i) out.args.push_back(primary(r->v.tuple.args[i]));
                 return out;
-            case MMABI_RHS_FILTER:
-                throw CompileError(std::string("filter `") + r->v.filter.filter->name +
-                                   "' is called without being inlined (recursion); not supported by the HIP backend yet");
-            default: throw CompileError("tree vectors are not supported by the HIP backend yet");
+            case MMABI_RHS_FILTER: {
+                // a call the reference's inliner left alone (can_inline, compiler.c:4219-4237: recursion): the callee's
+                // user values, then x, y, t (optimize_closure_application, compiler.c:3258-3275)
+                mmabi_filter_t *callee = r->v.filter.filter;
+                if (callee->kind != MMABI_FILTER_MATHMAP) throw CompileError("RHS_FILTER of a native filter");
+                out.kind = Rhs::FilterCall;
+                out.filter = filter(callee);
+                for (int i = 0; i < callee->num_uservals + 3; ++i) out.args.push_back(primary(r->v.filter.args[i]));
+                if (std::find(shared.called.begin(), shared.called.end(), callee) == shared.called.end()) shared.called.push_back(callee);
+                return out;
+            }
+            case MMABI_RHS_TREE_VECTOR:      // make_tree_vector_rhs (compiler.c:553-563) shares RHS_TUPLE's fields
+                out.kind = Rhs::TreeVector;
+                for (int i = 0; i < r->v.tuple.length; ++i) out.args.push_back(primary(r->v.tuple.args[i]));
+                return out;
+            default: throw CompileError("unknown rhs kind in the IR");
         }
     }
 
@@ -486,10 +504,29 @@ mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_i
         mmhip_filter *f = mmhip_filter_new_empty();
         try {
             f->code.reset(new FilterCode());
-            Importer imp(f->module, *f->code);
+            Importer::Shared shared;
+            Importer imp(f->module, *f->code, shared);
             f->module.main = imp.filter(mathmap->main_filter);
+            f->code->filter = f->module.main;
             imp.block(main_code->first_stmt, f->code->body, nullptr);
             imp.find_result();
+            propagate_types(*f->code);      // the types are the reference's; this fills in the tuple / tree-vector lengths
+            // filter_$name bodies of the filters called at run time, and of those they call (backends/cc.c:189-196
+            // prints every filter's code as a function; only the called ones are needed here)
+            for (size_t ci = 0; ci < shared.called.size(); ++ci) {
+                mmabi_filter_code_t *fc = nullptr;
+                int idx = 0;
+                for (mmabi_filter_t *g = mathmap->filters; g; g = g->next, ++idx)
+                    if (g == shared.called[ci]) fc = filter_codes[idx];
+                if (!fc) throw CompileError(std::string("filter `") + shared.called[ci]->name + "' is called but has no code");
+                std::unique_ptr<FilterCode> fn(new FilterCode());
+                fn->filter = imp.filter(shared.called[ci]);
+                Importer impf(f->module, *fn, shared);
+                impf.block(fc->first_stmt, fn->body, nullptr);
+                impf.find_result();
+                propagate_types(*fn);
+                f->code->functions.push_back(std::move(fn));
+            }
             std::string err;
             if (!mmhip_filter_finalize(f, k, &err)) throw CompileError(err);
             // user values arrive with every calc_lines call: specialise a kernel for a value set once it

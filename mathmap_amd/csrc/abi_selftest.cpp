@@ -187,15 +187,23 @@ struct Exporter {
                 r->v.closure.args = primary_arrays.back().data();
                 break;
             }
-            case Rhs::Tuple: {
-                r->kind = MMABI_RHS_TUPLE;
+            case Rhs::Tuple:
+            case Rhs::TreeVector: {
+                r->kind = s.kind == Rhs::Tuple ? MMABI_RHS_TUPLE : MMABI_RHS_TREE_VECTOR;
                 r->v.tuple.length = (int)s.args.size();
                 primary_arrays.emplace_back();
                 for (const Primary &p : s.args) primary_arrays.back().push_back(primary(p));
                 r->v.tuple.args = primary_arrays.back().data();
                 break;
             }
-            default: r->kind = MMABI_RHS_FILTER; break;
+            case Rhs::FilterCall: {
+                r->kind = MMABI_RHS_FILTER;
+                r->v.filter.filter = filter(s.filter);
+                primary_arrays.emplace_back();
+                for (const Primary &p : s.args) primary_arrays.back().push_back(primary(p));
+                r->v.filter.args = primary_arrays.back().data();
+                break;
+            }
         }
         return r;
     }
@@ -293,26 +301,39 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
         for (auto &f : m.filters) flist.push_back(ex.filter(f.get()));
         for (size_t i = 0; i + 1 < flist.size(); ++i) flist[i]->next = flist[i + 1];
 
+        // body + `tuple = (r,g,b,a); dummy = OUTPUT_TUPLE(tuple)` (compiler.c:4692-4697), for the main filter and
+        // for every filter it calls at run time (compiler_compile_filters hands the backend one code per filter)
+        auto export_code = [&](FilterCode &c, mmabi_filter_code_t &out) {
+            CompVar *tuple = c.new_var(Ty::Tuple);
+            tuple->tuple_len = 4;
+            Stmt *ta = c.new_stmt(Stmt::Assign);
+            ta->lhs = c.new_value(tuple);
+            ta->rhs.kind = Rhs::Tuple;
+            for (int i = 0; i < 4; ++i) ta->rhs.args.push_back(Primary::V(c.result[i]));
+            c.body.push_back(ta);
+            CompVar *dummy = c.new_var(Ty::Int);
+            Stmt *oa = c.new_stmt(Stmt::Assign);
+            oa->lhs = c.new_value(dummy);
+            oa->rhs = Rhs::O(op_by_cname("OUTPUT_TUPLE", 1), {Primary::V(ta->lhs)});
+            c.body.push_back(oa);
+            out.first_stmt = ex.block(c.body);
+        };
         mmabi_filter_code_t fc;
         fc.filter = ex.filter(m.main);
-        // body + `tuple = (r,g,b,a); dummy = OUTPUT_TUPLE(tuple)` (compiler.c:4692-4697)
-        CompVar *tuple = code->new_var(Ty::Tuple);
-        tuple->tuple_len = 4;
-        Stmt *ta = code->new_stmt(Stmt::Assign);
-        ta->lhs = code->new_value(tuple);
-        ta->rhs.kind = Rhs::Tuple;
-        for (int i = 0; i < 4; ++i) ta->rhs.args.push_back(Primary::V(code->result[i]));
-        code->body.push_back(ta);
-        CompVar *dummy = code->new_var(Ty::Int);
-        Stmt *oa = code->new_stmt(Stmt::Assign);
-        oa->lhs = code->new_value(dummy);
-        oa->rhs = Rhs::O(op_by_cname("OUTPUT_TUPLE", 1), {Primary::V(ta->lhs)});
-        code->body.push_back(oa);
-        fc.first_stmt = ex.block(code->body);
+        export_code(*code, fc);
+        std::deque<mmabi_filter_code_t> fn_codes;
+        for (auto &fn : code->functions) {
+            fn_codes.emplace_back();
+            fn_codes.back().filter = ex.filter(fn->filter);
+            export_code(*fn, fn_codes.back());
+        }
 
         std::vector<mmabi_filter_code_t *> codes(flist.size(), nullptr);
-        for (size_t i = 0; i < flist.size(); ++i)
+        for (size_t i = 0; i < flist.size(); ++i) {
             if (flist[i] == fc.filter) codes[i] = &fc;
+            for (mmabi_filter_code_t &c : fn_codes)
+                if (flist[i] == c.filter && !(c.filter == fc.filter)) codes[i] = &c;
+        }
 
         mmabi_mathmap_t mathmap;
         memset(&mathmap, 0, sizeof mathmap);

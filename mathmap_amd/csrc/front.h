@@ -20,9 +20,9 @@ namespace mm {
 
 struct CompileError : std::runtime_error {
     int pos;
-    // the failure goes away once the main filter's scalar user values are literals
-    // (recursion whose depth they control): the runtime then compiles per value set
-    bool needs_constants = false;
+    // lowering with baked-in user values unrolls recursion; this is set when that unrolling did not end
+    // (lower_filter then lowers again with run-time filter_$name calls)
+    bool recursion_limit = false;
     CompileError(const std::string &m, int p = -1) : std::runtime_error(m), pos(p) {}
 };
 

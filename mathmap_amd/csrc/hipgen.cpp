@@ -54,6 +54,17 @@ struct Generator {
 
     Generator(FilterCode &c, const KernelOptions &o) : code(c), opt(o) {}
 
+    // filter_$name functions (FilterCode::functions): `fn_root` is the code whose functions are callable,
+    // `in_function` is set while one of their bodies is printed
+    FilterCode *fn_root = nullptr;
+    bool in_function = false;
+    int function_index(const Filter *f) const {
+        const FilterCode *root = fn_root ? fn_root : &code;
+        for (size_t i = 0; i < root->functions.size(); ++i)
+            if (root->functions[i]->filter == f) return (int)i;
+        return -1;
+    }
+
     static std::string vname(const Value *v) {
         char buf[64];
         snprintf(buf, sizeof buf, "v%d_%d", v->var->id, v->index);
@@ -70,6 +81,9 @@ struct Generator {
             case Ty::Gradient: return "int";
             case Ty::Image: return "mm_image";
             case Ty::Tuple: return "mm_tup<" + std::to_string(v->tuple_len > 0 ? v->tuple_len : 4) + ">";
+            case Ty::TreeVector:       // a tree vector's length is static (ir.cpp propagate_types): `len' floats
+                if (v->tuple_len <= 0) throw CompileError("HIP backend: tree vector of unknown length");
+                return "mm_tup<" + std::to_string(v->tuple_len) + ">";
             default: throw CompileError(std::string("HIP backend: unsupported variable type ") + ty_name(v->type));
         }
     }
@@ -79,6 +93,7 @@ struct Generator {
             case Ty::Complex: return 8;
             case Ty::Image: return 24;
             case Ty::Tuple: return 4 * (v->tuple_len > 0 ? v->tuple_len : 4);
+            case Ty::TreeVector: return 4 * std::max(v->tuple_len, 1);
             default: return 4;
         }
     }
@@ -101,7 +116,8 @@ struct Generator {
                     switch (v->var->type) {
                         case Ty::Image: return "UNINITED_IMAGE";
                         case Ty::Complex: return "mm_cmake(0.0f, 0.0f)";
-                        case Ty::Tuple: return ctype(v->var) + "{}";
+                        case Ty::Tuple:
+                        case Ty::TreeVector: return ctype(v->var) + "{}";
                         default: return "0";
                     }
                 }
@@ -142,7 +158,8 @@ struct Generator {
         switch (r.kind) {
             case Rhs::Prim: return prim(r.prim, sl);
             case Rhs::Internal: return r.internal;
-            case Rhs::Tuple: {
+            case Rhs::Tuple:
+            case Rhs::TreeVector: {      // backends/cc.c:287-300: float tuple[n] = { args }; ALLOC_TREE_VECTOR(n, tuple)
                 std::string s = "mm_tup<" + std::to_string(r.args.size()) + ">{{";
                 for (size_t i = 0; i < r.args.size(); ++i) s += (i ? ", (float)(" : "(float)(") + prim(r.args[i], sl) + ")";
                 return s + "}}";
@@ -161,7 +178,24 @@ struct Generator {
                 for (size_t i = r.args.size(); i < 4; ++i) s += ", mm_narg(0)";
                 return s + ")";
             }
-            case Rhs::FilterCall: throw CompileError("HIP backend: non-inlined filter calls are not supported");
+            case Rhs::FilterCall: {
+                // backends/cc.c:221-235: build the callee's argument block (output_make_mathmap_filter_closure), call
+                // filter_$name(invocation, image, x, y, t, pools).  Here a statement expression around a template
+                // instance: the template parameter is the call depth, so the call graph is a finite DAG (see emit_functions)
+                const int k = function_index(r.filter);
+                if (k < 0) throw CompileError("internal: call of filter `" + r.filter->name + "' without a function body");
+                const size_t n = r.filter->uservals.size();
+                if (r.args.size() != n + 3) throw CompileError("internal: malformed filter call");
+                std::string e = "({ mm_uvarg mm_ca[" + std::to_string(n ? n : 1) + "]; ";
+                for (size_t i = 0; i < n; ++i) {
+                    const UservalInfo &u = r.filter->uservals[i];
+                    const char *field = u.kind == UvKind::Float ? ".f = (float)(" : u.kind == UvKind::Color ? ".c = (color_t)(" : u.kind == UvKind::Image ? ".img = (" : ".i = (int)(";
+                    e += "mm_ca[" + std::to_string(u.index) + "]" + field + prim(r.args[i], sl) + "); ";
+                }
+                e += "mm_filter_" + std::to_string(k) + "<" + (in_function ? "MM_D + 1" : "0") + ">(A, mm_ca, (float)(" + prim(r.args[n], sl) +
+                     "), (float)(" + prim(r.args[n + 1], sl) + "), (float)(" + prim(r.args[n + 2], sl) + "), col, rl, mm_rand_ctr); })";
+                return e;
+            }
             case Rhs::Op: {
                 const char *cn = r.op->cname;
                 if (!strcmp(cn, "RENDER")) {
@@ -174,10 +208,15 @@ struct Generator {
                            "), mm_narg(" + prim(r.args[2], sl) + "), mm_narg(0))";
                 }
                 for (const char *bad : {"SOLVE_POLY_2", "SOLVE_POLY_3",      // unimplemented stubs in the reference too (opmacros.h:97-99)
-                                        "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH", "START_DEBUG_TUPLE",
+                                        "START_DEBUG_TUPLE",
                                         "SET_DEBUG_TUPLE_DATA", "OUTPUT_TUPLE"})
                     if (!strcmp(cn, bad)) throw CompileError(std::string("HIP backend: op ") + cn + " is not supported yet");
                 if (!strcmp(cn, "PRINT_FLOAT") || !strcmp(cn, "NEWLINE")) return "0";
+                // opmacros.h:189-190: the index is passed to a C `int' parameter (converted like FLOAT2INT), the value to a float
+                if (!strcmp(cn, "TREE_VECTOR_NTH"))
+                    return "mm_tv_nth(FLOAT2INT(" + prim(r.args[0], sl) + "), " + prim(r.args[1], sl) + ")";
+                if (!strcmp(cn, "SET_TREE_VECTOR_NTH"))
+                    return "mm_tv_set(FLOAT2INT(" + prim(r.args[0], sl) + "), " + prim(r.args[1], sl) + ", (float)(" + prim(r.args[2], sl) + "))";
                 // escape-time test `sqrt(a) < 2^k`  ->  0 <= a < 4^k (exact, see mm_device.h)
                 if (opt.fast_math_exact && !strcmp(cn, "LESS") && r.args[0].kind == Primary::Val && r.args[1].is_const()) {
                     const Stmt *d = r.args[0].value->def;
@@ -211,6 +250,12 @@ struct Generator {
                     const float c = r.args[1].f;
                     if (std::isfinite(c) && c != 0.0f && std::fabs(std::frexp(c, &ex)) == 0.5f && ex > -100 && ex < 100)
                         return "((float)(" + prim(r.args[0], sl) + ") * " + float_literal(1.0f / c) + "f)";
+                }
+                if (in_function && !strncmp(cn, "USERVAL_", 8) && r.args.size() == 1 && r.args[0].kind == Primary::IntConst) {
+                    // inside filter_$name the user values are the call's arguments (new_template.c.in:375-422: the closure's args)
+                    const char *field = !strcmp(cn, "USERVAL_FLOAT_ACCESS") ? "f" : !strcmp(cn, "USERVAL_COLOR_ACCESS") ? "c"
+                                      : !strcmp(cn, "USERVAL_IMAGE_ACCESS") ? "img" : "i";
+                    return "(UV[" + std::to_string(r.args[0].i) + "]." + field + ")";
                 }
                 std::string name = cn;
                 if (const char *lm = libm_name(cn)) name = lm;
@@ -1000,7 +1045,9 @@ struct Generator {
                "#define MMQ_SQRTF(a) sqrtf((a))\n"
             << device_fastmath_prelude() << "\n";
         out << device_prelude() << "\n";
-        if (uses_noise(code.body)) {
+        bool noise = uses_noise(code.body);
+        for (auto &fn : (fn_root ? fn_root : &code)->functions) noise = noise || uses_noise(fn->body);
+        if (noise) {
             if (!noise_table_text())
                 throw CompileError("the noise builtins need libnoise's gradient table, which was not available when this "
                                    "library was built (see tools/extract_noise_table.py)");
@@ -1036,6 +1083,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
     const int __renderPixelW = A.render_width, __renderPixelH = A.render_height; \
     (void)t; (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;
 )";
+        emit_functions();
         // ---- prologue ----
         ks.prologue_uses_time = hoisted_uses_time(code.body);
         ks.prologue_name = "mm_prologue";
@@ -1045,6 +1093,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                "    if (gid < A.region_width) A.xtab[gid] = CALC_VIRTUAL_X(gid + A.region_x, A.frame_render_width, A.sampling_offset_x);\n"
                "    if (gid < A.num_rows) A.ytab[gid] = CALC_VIRTUAL_Y(A.first_row + gid, A.frame_render_height, A.sampling_offset_y);\n"
                "    if (gid != 0) return;\n  }\n  MM_INTERNALS\n";
+        if (!(fn_root ? fn_root : &code)->functions.empty()) out << "  const int col = 0, rl = 0; unsigned mm_rand_ctr = 0; (void)col; (void)rl; (void)mm_rand_ctr;\n";
         decls(pro_defs, "  ");
         stmts(code.body, PROLOGUE, "  ");
         for (Value *v : transfer_order)
@@ -1187,6 +1236,45 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         finish_source();
     }
 
+    // filter_$name of every filter that is called at run time.  The reference's are ordinary recursive C functions;
+    // a GPU kernel wants a stack bound it can prove, so each is a template on the call depth: depth D calls depth
+    // D + 1, and depth MM_MAX_CALL_DEPTH returns the zero tuple without evaluating anything -- the call graph is
+    // a finite DAG, the compiler computes the exact stack need, nothing can overflow.  (A recursion deeper than
+    // that is cut off; the reference would keep going until its C stack overflows.)
+    void emit_functions() {
+        FilterCode &root = fn_root ? *fn_root : code;
+        if (root.functions.empty()) return;
+        out << "#ifndef MM_MAX_CALL_DEPTH\n#define MM_MAX_CALL_DEPTH " << (getenv("MMHIP_MAX_CALL_DEPTH") ? atoi(getenv("MMHIP_MAX_CALL_DEPTH")) : 16)
+            << "\n#endif\n"
+               "struct mm_uvarg { int i; float f; color_t c; mm_image img; };\n";
+        for (size_t k = 0; k < root.functions.size(); ++k)
+            out << "template <int MM_D> __device__ __noinline__ mm_tup<4> mm_filter_" << k
+                << "(const mm_args &A, const mm_uvarg *UV, float x, float y, float t, int col, int rl, unsigned &mm_rand_ctr);\n";
+        for (size_t k = 0; k < root.functions.size(); ++k) {
+            FilterCode &fn = *root.functions[k];
+            Generator g(fn, opt);
+            g.fn_root = &root;
+            g.in_function = true;
+            std::vector<Value *> defs;
+            std::set<Value *> uses;
+            g.collect_values(fn.body, PIXEL, defs, uses);
+            out << "// filter_" << (fn.filter ? fn.filter->name : "") << "\n"
+                << "template <int MM_D> __device__ __noinline__ mm_tup<4> mm_filter_" << k
+                << "(const mm_args &A, const mm_uvarg *UV, float x, float y, float t, int col, int rl, unsigned &mm_rand_ctr) {\n"
+                   "  mm_tup<4> rt;\n  rt.v[0] = rt.v[1] = rt.v[2] = rt.v[3] = 0.0f;\n"
+                   "  if constexpr (MM_D >= MM_MAX_CALL_DEPTH) { return rt; } else {\n"
+                   "  const float R = A.R; const int frame = A.frame;\n"
+                   "  const int __canvasPixelW = A.img_width, __canvasPixelH = A.img_height;\n"
+                   "  const int __renderPixelW = A.render_width, __renderPixelH = A.render_height;\n"
+                   "  (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;\n";
+            g.decls(defs, "  ");
+            g.stmts(fn.body, PIXEL, "  ");
+            out << g.out.str();
+            for (int i = 0; i < 4; ++i) out << "  rt.v[" << i << "] = " << g.prim(Primary::V(fn.result[i]), PIXEL) << ";\n";
+            out << "  return rt;\n  }\n}\n";
+        }
+    }
+
     void finish_source() {
         ks.source = out.str();
         char buf[32];
@@ -1197,8 +1285,9 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
 
 }  // namespace
 
-KernelSource generate_hip(FilterCode &code, const KernelOptions &opt) {
+KernelSource generate_hip(FilterCode &code, const KernelOptions &opt, FilterCode *functions_of) {
     Generator g(code, opt);
+    g.fn_root = functions_of;
     g.run();
     return std::move(g.ks);
 }

@@ -41,7 +41,8 @@ struct KernelSource {
     std::string key;              // cache key (hash of source)
 };
 
-KernelSource generate_hip(FilterCode &code, const KernelOptions &opt);
+// `functions_of`: the code whose `functions` (filter_$name bodies) `code` may call; null = its own
+KernelSource generate_hip(FilterCode &code, const KernelOptions &opt, FilterCode *functions_of = nullptr);
 const char *device_prelude();
 const char *device_noise_prelude();   // mm_noise_device.h
 const char *device_fastmath_prelude();   // mm_fastmath.h + tables

@@ -208,6 +208,7 @@ Ty Rhs::type() const {
         case Tuple:
         case FilterCall: return Ty::Tuple;
         case Closure: return Ty::Image;
+        case TreeVector: return Ty::TreeVector;
         default: return Ty::Nil;
     }
 }
@@ -263,6 +264,19 @@ static bool propagate_block(Block &b) {
                 if ((int)t > (int)s->lhs->var->type) {
                     s->lhs->var->type = t;
                     changed = true;
+                }
+                if (t == Ty::TreeVector && s->lhs->var->tuple_len == 0) {
+                    // the length of a tree vector is static: it comes from the RHS_TREE_VECTOR that built it and
+                    // travels through copies, phis and SET_TREE_VECTOR_NTH
+                    auto len_of = [](const Rhs &r) {
+                        if (r.kind == Rhs::TreeVector) return (int)r.args.size();
+                        if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val) return r.prim.value->var->tuple_len;
+                        if (r.kind == Rhs::Op && r.args.size() == 3 && r.args[1].kind == Primary::Val) return r.args[1].value->var->tuple_len;
+                        return 0;
+                    };
+                    int len = len_of(s->rhs);
+                    if (!len && s->kind == Stmt::Phi) len = len_of(s->rhs2);
+                    if (len) { s->lhs->var->tuple_len = len; changed = true; }
                 }
                 if (t == Ty::Tuple && s->lhs->var->tuple_len == 0) {
                     int len = 0;
@@ -342,7 +356,8 @@ void js_rhs(std::ostringstream &o, const Rhs &r) {
             o << "]}";
             break;
         case Rhs::Tuple:
-            o << "{\"k\":\"tuple\",\"args\":[";
+        case Rhs::TreeVector:
+            o << "{\"k\":\"" << (r.kind == Rhs::Tuple ? "tuple" : "treevector") << "\",\"args\":[";
             for (size_t i = 0; i < r.args.size(); ++i) { if (i) o << ","; js_prim(o, r.args[i]); }
             o << "]}";
             break;
@@ -442,6 +457,11 @@ std::string dump_ir(const FilterCode &code) {
         else o << "null";
     }
     o << "]";
+    if (!code.functions.empty()) {
+        o << ",\"functions\":[";
+        for (size_t i = 0; i < code.functions.size(); ++i) { if (i) o << ","; o << dump_ir(*code.functions[i]); }
+        o << "]";
+    }
     if (!code.closure_renders.empty()) {
         o << ",\"closure_renders\":[";
         for (size_t i = 0; i < code.closure_renders.size(); ++i) { if (i) o << ","; o << dump_ir(*code.closure_renders[i]); }

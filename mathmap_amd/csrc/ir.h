@@ -55,7 +55,7 @@ struct CompVar {
     bool is_temp = true;
     std::string name;      // user variable name (empty for temporaries)
     int elem = 0;          // tuple element index of a user variable
-    int tuple_len = 0;     // only for Ty::Tuple
+    int tuple_len = 0;     // only for Ty::Tuple and Ty::TreeVector (its static length)
     Value *current = nullptr;
     std::vector<Value *> values;
 };
@@ -86,11 +86,11 @@ struct Primary {
 };
 
 struct Rhs {
-    enum Kind { None, Prim, Internal, Op, Closure, Tuple, FilterCall } kind = None;
+    enum Kind { None, Prim, Internal, Op, Closure, Tuple, FilterCall, TreeVector } kind = None;
     Primary prim;                 // Prim
     std::string internal;         // Internal
     const OpInfo *op = nullptr;   // Op
-    std::vector<Primary> args;    // Op / Closure / Tuple / FilterCall
+    std::vector<Primary> args;    // Op / Closure / Tuple / FilterCall / TreeVector
     Filter *filter = nullptr;     // Closure / FilterCall
     static Rhs P(Primary p) { Rhs r; r.kind = Prim; r.prim = p; return r; }
     static Rhs V(Value *v) { return P(Primary::V(v)); }
@@ -165,6 +165,11 @@ struct FilterCode {
     // render_image's calc_lines(..., floatmap = 1) launch computes).  The runtime renders it into the
     // native filter's input map before the native filter runs.
     std::vector<std::unique_ptr<FilterCode>> closure_renders;
+    // filter_$name of the filters that are called at run time (new_template.c.in:375-422): a call the
+    // compiler does not inline -- recursion: the callee is already on the inlining stack, compiler.c:4219-4237 --
+    // stays an Rhs::FilterCall (the reference's RHS_FILTER: closure arguments, then x, y, t), and its
+    // callee is compiled once as a function of (arguments, x, y, t).  functions[i]->filter is the callee.
+    std::vector<std::unique_ptr<FilterCode>> functions;
 
     CompVar *new_var(Ty t, const std::string &name = "", int elem = 0);
     Value *new_value(CompVar *v);

@@ -145,6 +145,7 @@ struct Loader {
             return r;
         }
         if (k == "tuple") { r.kind = Rhs::Tuple; args(r); return r; }
+        if (k == "treevector") { r.kind = Rhs::TreeVector; args(r); return r; }
         if (k == "closure") {
             r.kind = Rhs::Closure;
             args(r);
@@ -158,6 +159,14 @@ struct Loader {
                 r.filter = mod.filters.back().get();
                 r.filter->name = j["filter"].str;
             }
+            return r;
+        }
+        if (k == "filtercall") {
+            r.kind = Rhs::FilterCall;
+            args(r);
+            for (auto &f : mod.filters)
+                if (f->kind == Filter::MathMap && f->name == j["filter"].str) r.filter = f.get();
+            if (!r.filter) throw CompileError("IR JSON: call of unknown filter " + j["filter"].str);
             return r;
         }
         throw CompileError("IR JSON: unsupported rhs kind " + k);
@@ -238,6 +247,35 @@ struct Loader {
         }
         mod.main = f;
         code.filter = f;
+        // filters called at run time: their Filter objects first (calls refer to them by name), bodies below
+        std::vector<Filter *> fn_filters;
+        for (const J &fn : root["functions"].arr) {
+            Filter *ff = nullptr;
+            if (fn["filter"].str == f->name) ff = f;            // the main filter calling itself
+            else {
+                mod.filters.emplace_back(new Filter());
+                ff = mod.filters.back().get();
+                ff->name = fn["filter"].str;
+                ff->flags = (unsigned)fn["flags"].i();
+                for (const J &u : fn["uservals"].arr) {
+                    UservalInfo ui;
+                    ui.index = (int)u["index"].i();
+                    ui.kind = (UvKind)u["kind"].i();
+                    ui.name = u["name"].str;
+                    ui.imin = (int)u["imin"].i(); ui.imax = (int)u["imax"].i(); ui.idef = (int)u["idef"].i();
+                    ui.fmin = (float)u["fmin"].num; ui.fmax = (float)u["fmax"].num; ui.fdef = (float)u["fdef"].num;
+                    ui.bdef = u["bdef"].i() != 0;
+                    ui.image_flags = (unsigned)u["image_flags"].i();
+                    ff->uservals.push_back(ui);
+                }
+            }
+            fn_filters.push_back(ff);
+        }
+        for (size_t i = 0; i < fn_filters.size(); ++i) {
+            code.functions.emplace_back(new FilterCode());
+            Loader lf(mod, *code.functions.back());
+            lf.load_sub(root["functions"][i], fn_filters[i]);
+        }
         for (const J &v : root["vars"].arr) {
             CompVar *cv = code.new_var(type_of(v["type"].str), v["name"].str, (int)v["elem"].i());
             cv->tuple_len = (int)v["tuple_len"].i();

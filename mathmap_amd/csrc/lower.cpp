@@ -40,6 +40,9 @@ class Lowerer {
     Lowerer(Module &m, FilterCode &code) : m_(m), code_(code), g_(code) {}
     const std::map<int, Primary> *uv_consts_ = nullptr;
     void run(Filter *f);
+    void run_function(Filter *f);
+    bool unroll_recursion_ = false;     // user values are literals: unroll recursive applications instead of calling
+    std::vector<Filter *> called_;      // filters reached through Rhs::FilterCall (each needs a function body)
     // closure images handed to native filters (render_image's closure branch)
     int render_target_ = -1;        // >= 0: lower "closure #render_target_ applied at (x, y), t = 0" as the result
     int closure_counter_ = 0;       // closures numbered in the order their first native use is lowered
@@ -81,8 +84,7 @@ class Lowerer {
     // tree vectors (dynamic tuple subscripts), lowered to element variables + select chains
     std::set<const AstNode *> vector_selects_;
     void find_vector_variables(AstNode *n);
-    CompVar *clamped_index(AstNode *sub, int len);
-    CompVar *dynamic_read(const std::vector<CompVar *> &elems, CompVar *idx);
+    CompVar *gen_tree_vector(AstNode *tree, CompVar **dest, bool alloced);
     void to_float(CompVar *dst, CompVar *src) { g_.assign_op(dst, "INT2FLOAT", {g_.P(src)}); }
     ImageChain resolve_image(Value *v);
     void alloc_var(Variable *v);
@@ -183,27 +185,34 @@ void Lowerer::reset_vars(FilterVars *fv) {
     for (auto &v : fv->vars) v->compvar.assign(v->type.len, nullptr);
 }
 
+// compiler.c:1775-1790 alloc_var_compvars_if_needed
 void Lowerer::alloc_var(Variable *v) {
+    if (v->is_vector) {       // one compvar holding the whole vector (make_tree_vector_variable, compiler.c:303-316)
+        if (!v->compvar[0]) {
+            v->compvar[0] = code_.new_var(Ty::TreeVector, v->name, 0);
+            v->compvar[0]->tuple_len = v->type.len;
+        }
+        return;
+    }
     for (int i = 0; i < v->type.len; ++i)
         if (!v->compvar[i]) {
             bool is_image = v->type.tag == m_.tags.image && v->type.len == 1;
-            v->compvar[i] = code_.new_var(is_image ? Ty::Image : v->is_vector ? Ty::Float : Ty::Int, v->name, i);
+            v->compvar[i] = code_.new_var(is_image ? Ty::Image : Ty::Int, v->name, i);
         }
 }
 
 // compiler.c:2610-2664.  `args` = closure arguments followed by x, y, t for an
 // inlined call; nullptr for the main filter.
 void Lowerer::gen_filter(Filter *f, const std::vector<Primary> *args, CompVar *result[4]) {
-    // Filter calls are inlined, so recursion must bottom out while lowering: an `if' whose
-    // condition folds to a literal (const_value) only lowers the taken branch.  The reference
-    // calls filter_<name> recursively at run time (compiler.c:2165-2222, backends/cc.c:189);
-    // here the recursion depth has to be fixed by literals or baked-in user values.
+    // A recursive application stays a run-time call of filter_$name (gen_func; compiler.c:2165-2222, backends/cc.c:189)
+    // unless the user values are baked in: then it is unrolled here -- an `if' whose condition folds to a literal
+    // (const_value) only lowers the taken branch -- which gives a kernel without calls.  An unrolling that does
+    // not end is reported to lower_filter, which lowers again with calls.
     int active = 0;
     for (Filter *h : inlining_) active += h == f;
     if (active >= MAX_RECURSION) {
-        CompileError e("recursive filter `" + f->name + "': the recursion does not end for compile-time-constant "
-                       "arguments (the HIP backend unrolls recursion, its depth must be fixed by the user values)");
-        e.needs_constants = uv_consts_ == nullptr;
+        CompileError e("recursive filter `" + f->name + "': the recursion does not end for compile-time-constant arguments");
+        e.recursion_limit = true;
         throw e;
     }
     inlining_.push_back(f);
@@ -294,11 +303,10 @@ bool Lowerer::single_const(AstNode *n, int *iv) {
 }
 
 // compiler.c:2521-2600 (find_all_vector_variables): a variable that is subscripted with a
-// non-constant index anywhere in the filter is a "tree vector" everywhere in it.  The reference
-// stores such a variable as a persistent tree of floats (tree_vectors.c) with clamped indices; the
-// tuple length is static, so here it stays `len` float element variables: a dynamic read is a
-// chain of conditional copies, a dynamic write a chain of conditional stores -- same values
-// (elements are converted to float on every store, like the C float array; reads are floats).
+// non-constant index anywhere in the filter is a "tree vector" everywhere in it: one TYPE_TREE_VECTOR
+// compvar, read with TREE_VECTOR_NTH, written with SET_TREE_VECTOR_NTH (a new vector value per write),
+// built from element values by RHS_TREE_VECTOR.  The reference stores it as a persistent tree of floats
+// (tree_vectors.c); its length is static, so the kernels keep it as `len` floats in registers.
 void Lowerer::find_vector_variables(AstNode *n) {
     if (!n) return;
     for (AstNode *k : n->kids) find_vector_variables(k);
@@ -316,32 +324,26 @@ void Lowerer::find_vector_variables(AstNode *n) {
     }
 }
 
-// TREE_VECTOR_NTH / SET_TREE_VECTOR_NTH take the index as a C int and clamp it (tree_vectors.c:96-99)
-CompVar *Lowerer::clamped_index(AstNode *sub, int len) {
-    std::vector<CompVar *> sv = gen_new(sub);
-    CompVar *idx = g_.temp();
-    g_.assign_op(idx, "FLOAT2INT", {g_.P(sv[0])});
-    g_.start_if(Rhs::O(g_.op("LESS", 2), {g_.P(idx), Primary::I(0)}));
-    g_.assign(idx, Rhs::I(0));
-    g_.switch_branch();
-    g_.end_if();
-    g_.start_if(Rhs::O(g_.op("LESS", 2), {Primary::I(len - 1), g_.P(idx)}));
-    g_.assign(idx, Rhs::I(len - 1));
-    g_.switch_branch();
-    g_.end_if();
-    return idx;
-}
-
-CompVar *Lowerer::dynamic_read(const std::vector<CompVar *> &elems, CompVar *idx) {
-    CompVar *r = g_.temp(Ty::Float);
-    g_.copy(r, elems[0]);
-    for (size_t k = 1; k < elems.size(); ++k) {
-        g_.start_if(Rhs::O(g_.op("EQ", 2), {g_.P(idx), Primary::I((int)k)}));
-        g_.copy(r, elems[k]);
-        g_.switch_branch();
-        g_.end_if();
+// compiler.c:1839-1873 gen_tree_vector: the vector holding the value of `tree`, whose elements go to `dest`
+CompVar *Lowerer::gen_tree_vector(AstNode *tree, CompVar **dest, bool alloced) {
+    const int len = tree->result.len;
+    if (tree->kind == AstNode::Var && tree->var->is_vector) {
+        alloc_var(tree->var);
+        CompVar *tv = tree->var->compvar[0];
+        for (int i = 0; i < len; ++i) {
+            if (!alloced) dest[i] = g_.temp(Ty::Float);
+            g_.assign_op(dest[i], "TREE_VECTOR_NTH", {Primary::I(i), g_.P(tv)});
+        }
+        return tv;
     }
-    return r;
+    gen(tree, dest, alloced);
+    Rhs r;
+    r.kind = Rhs::TreeVector;
+    for (int i = 0; i < len; ++i) r.args.push_back(g_.P(dest[i]));
+    CompVar *tv = g_.temp(Ty::TreeVector);
+    tv->tuple_len = len;
+    g_.assign(tv, r);
+    return tv;
 }
 
 // The literal an SSA value is known to hold while lowering (copies and foldable ops of
@@ -524,8 +526,27 @@ void Lowerer::gen_func(AstNode *n, CompVar **dest, bool alloced) {
             cargs.push_back(g_.P(x));
             cargs.push_back(g_.P(y));
             cargs.push_back(g_.P(args[1][0]));
+            Filter *callee = chain.closure_def->rhs.filter;
+            bool recursive = false;
+            for (Filter *h : inlining_) recursive = recursive || h == callee;
+            if (recursive && !unroll_recursion_) {
+                // compiler.c:4219-4237 can_inline: a filter that is already being inlined is not inlined again --
+                // the application stays a call of filter_$name (RHS_FILTER), evaluated at run time
+                Rhs call;
+                call.kind = Rhs::FilterCall;
+                call.filter = callee;
+                call.args = cargs;
+                CompVar *tv = g_.temp(Ty::Tuple);
+                tv->tuple_len = 4;
+                g_.assign(tv, call);
+                for (int i = 0; i < 4; ++i) g_.assign_op(result[i], "TUPLE_NTH", {g_.P(tv), Primary::I(i)});
+                bool known = false;
+                for (Filter *c : called_) known = known || c == callee;
+                if (!known) called_.push_back(callee);
+                return;
+            }
             CompVar *res[4];
-            gen_filter(chain.closure_def->rhs.filter, &cargs, res);
+            gen_filter(callee, &cargs, res);
             for (int i = 0; i < 4; ++i) g_.copy(result[i], res[i]);
             return;
         }
@@ -548,23 +569,18 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
         case AstNode::Tuple:
             for (size_t i = 0; i < n->kids.size(); ++i) gen(n->kids[i], dest + i, alloced);
             break;
-        case AstNode::Select: {
-            std::vector<CompVar *> temps = gen_new(n->kids[0]);
+        case AstNode::Select: {      // compiler.c:1911-1958
             int len = n->kids[0]->result.len;
-            if (vector_selects_.count(n) && !(n->kids[0]->kind == AstNode::Var && n->kids[0]->var->is_vector)) {
-                // dynamic subscript of an expression: gen_tree_vector builds a float vector of its value
-                for (CompVar *&tv : temps) {
-                    CompVar *f = g_.temp(Ty::Float);
-                    to_float(f, tv);
-                    tv = f;
-                }
-            }
+            std::vector<CompVar *> temps(len, nullptr);
+            CompVar *tv = nullptr;
+            if (vector_selects_.count(n)) tv = gen_tree_vector(n->kids[0], temps.data(), false);
+            else temps = gen_new(n->kids[0]);
             for (size_t i = 0; i < n->subs.size(); ++i) {
                 int sub;
                 if (!single_const(n->subs[i], &sub)) {
-                    CompVar *r = dynamic_read(temps, clamped_index(n->subs[i], len));
-                    if (!alloced) dest[i] = r;
-                    else g_.copy(dest[i], r);
+                    std::vector<CompVar *> sv = gen_new(n->subs[i]);
+                    if (!alloced) dest[i] = g_.temp();
+                    g_.assign_op(dest[i], "TREE_VECTOR_NTH", {g_.P(sv[0]), g_.P(tv)});
                     continue;
                 }
                 if (sub < 0) sub = 0;
@@ -576,6 +592,13 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
         }
         case AstNode::Var:
             alloc_var(n->var);
+            if (n->var->is_vector) {      // compiler.c:1962-1970
+                for (int i = 0; i < n->var->type.len; ++i) {
+                    if (!alloced) dest[i] = g_.temp();
+                    g_.assign_op(dest[i], "TREE_VECTOR_NTH", {Primary::I(i), g_.P(n->var->compvar[0])});
+                }
+                break;
+            }
             for (int i = 0; i < n->var->type.len; ++i) {
                 if (!alloced) dest[i] = n->var->compvar[i];
                 else g_.copy(dest[i], n->var->compvar[i]);
@@ -590,13 +613,9 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
         }
         case AstNode::Assign:
             alloc_var(n->var);
-            if (n->var->is_vector) {      // compiler.c:1995-1999: the value, then a float vector built from it
-                std::vector<CompVar *> vals = gen_new(n->kids[0]);
-                for (int i = 0; i < n->result.len; ++i) {
-                    to_float(n->var->compvar[i], vals[i]);
-                    if (alloced) g_.copy(dest[i], vals[i]);
-                    else dest[i] = vals[i];
-                }
+            if (n->var->is_vector) {      // compiler.c:1995-1999
+                CompVar *tv = gen_tree_vector(n->kids[0], dest, alloced);
+                g_.copy(n->var->compvar[0], tv);
                 break;
             }
             gen(n->kids[0], n->var->compvar.data(), true);
@@ -612,15 +631,9 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
             for (size_t i = 0; i < n->subs.size(); ++i) {
                 int sub;
                 if (n->var->is_vector) {      // SET_TREE_VECTOR_NTH, also for constant subscripts (compiler.c:2027-2038)
-                    CompVar *idx = clamped_index(n->subs[i], len);
-                    CompVar *fv = g_.temp(Ty::Float);
-                    to_float(fv, temps[i]);
-                    for (int k = 0; k < len; ++k) {
-                        g_.start_if(Rhs::O(g_.op("EQ", 2), {g_.P(idx), Primary::I(k)}));
-                        g_.copy(n->var->compvar[k], fv);
-                        g_.switch_branch();
-                        g_.end_if();
-                    }
+                    std::vector<CompVar *> sv = gen_new(n->subs[i]);
+                    CompVar *tv = n->var->compvar[0];
+                    g_.assign_op(tv, "SET_TREE_VECTOR_NTH", {g_.P(sv[0]), g_.P(tv), g_.P(temps[i])});
                     if (alloced) g_.copy(dest[i], temps[i]);
                     else dest[i] = temps[i];
                     continue;
@@ -707,6 +720,34 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
     }
 }
 
+// filter_$name (new_template.c.in:375-422): the filter as a function of its closure arguments and (x, y, t).  The
+// arguments are read with the USERVAL_*_ACCESS operators -- inside a function body they index the call's
+// argument block instead of the invocation's user values -- and x, y, t are the internals of that name, which are
+// the function's parameters there.  Same code path as an inlined application (gen_filter with arguments).
+void Lowerer::run_function(Filter *f) {
+    static const char *getters[] = {"USERVAL_INT_ACCESS", "USERVAL_FLOAT_ACCESS", "USERVAL_BOOL_ACCESS", "USERVAL_COLOR_ACCESS",
+                                    "USERVAL_CURVE_ACCESS", "USERVAL_GRADIENT_ACCESS", "USERVAL_IMAGE_ACCESS"};
+    Env env;                       // internal_value needs an environment before gen_filter makes the callee's
+    env.filter = f;
+    env_ = &env;
+    std::vector<Primary> cargs;
+    for (const UservalInfo &u : f->uservals) {
+        Ty ty = u.kind == UvKind::Float ? Ty::Float : u.kind == UvKind::Color ? Ty::Color
+              : u.kind == UvKind::Curve ? Ty::Curve : u.kind == UvKind::Gradient ? Ty::Gradient
+              : u.kind == UvKind::Image ? Ty::Image : Ty::Int;
+        CompVar *a = g_.temp(ty);
+        g_.assign_op(a, getters[(int)u.kind], {Primary::I(u.index)});
+        cargs.push_back(g_.P(a));
+    }
+    cargs.push_back(Primary::V(internal_value("x", false)));
+    cargs.push_back(Primary::V(internal_value("y", false)));
+    cargs.push_back(Primary::V(internal_value("t", false)));
+    env_ = nullptr;
+    CompVar *res[4];
+    gen_filter(f, &cargs, res);
+    for (int i = 0; i < 4; ++i) code_.result[i] = res[i]->current;
+}
+
 void Lowerer::run(Filter *f) {
     CompVar *res[4];
     gen_filter(f, nullptr, res);
@@ -719,12 +760,13 @@ void Lowerer::run(Filter *f) {
 
 }  // namespace
 
-std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<int, Primary> *uv_consts) {
+static std::unique_ptr<FilterCode> lower_filter_impl(Module &m, Filter *f, const std::map<int, Primary> *uv_consts, bool unroll) {
     if (f->kind != Filter::MathMap) throw CompileError("cannot lower a native filter");
     std::unique_ptr<FilterCode> code(new FilterCode());
     code->filter = f;
     Lowerer l(m, *code);
     l.uv_consts_ = uv_consts;
+    l.unroll_recursion_ = unroll;
     l.run(f);
     propagate_types(*code);
     for (int k = 0; k < l.closure_counter_; ++k) {
@@ -732,12 +774,44 @@ std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<in
         sub->filter = f;
         Lowerer ls(m, *sub);
         ls.uv_consts_ = uv_consts;
+        ls.unroll_recursion_ = unroll;
         ls.render_target_ = k;
         ls.run(f);
         propagate_types(*sub);
         code->closure_renders.push_back(std::move(sub));
+        for (Filter *c : ls.called_) {
+            bool known = false;
+            for (Filter *k2 : l.called_) known = known || k2 == c;
+            if (!known) l.called_.push_back(c);
+        }
+    }
+    // function bodies of the filters called at run time, and of those they call
+    std::vector<Filter *> work = l.called_;
+    for (size_t i = 0; i < work.size(); ++i) {
+        std::unique_ptr<FilterCode> fn(new FilterCode());
+        fn->filter = work[i];
+        Lowerer lf(m, *fn);
+        lf.run_function(work[i]);
+        propagate_types(*fn);
+        for (Filter *c : lf.called_) {
+            bool known = false;
+            for (Filter *k2 : work) known = known || k2 == c;
+            if (!known) work.push_back(c);
+        }
+        code->functions.push_back(std::move(fn));
     }
     return code;
+}
+
+std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<int, Primary> *uv_consts) {
+    if (uv_consts) {
+        try {
+            return lower_filter_impl(m, f, uv_consts, true);
+        } catch (const CompileError &e) {
+            if (!e.recursion_limit) throw;
+        }
+    }
+    return lower_filter_impl(m, f, uv_consts, false);
 }
 
 }  // namespace mm

@@ -366,6 +366,22 @@ MM_DEV mm_complex cgamma(mm_complex zf) {
 #define MAKE_COLOR(r, g, b, a) \
     (MAKE_RGBA_COLOR(CLAMP01((r)) * 255, CLAMP01((g)) * 255, CLAMP01((b)) * 255, CLAMP01((a)) * 255))
 #define TUPLE_NTH(t, n) ((t).v[(n)])
+// Tree vectors (tree_vectors.c:89-108 tree_vector_get, :110-150 tree_vector_set): indices are clamped to the vector,
+// a write makes a new vector.  The length is static, so a vector is N floats in registers and a run-time index
+// is a chain of selects (a dynamically indexed array would go to scratch memory).
+template <int N> MM_DEV float mm_tv_nth(int i, const mm_tup<N> &tv) {
+    i = i < 0 ? 0 : (i >= N ? N - 1 : i);
+    float r = tv.v[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) r = i == k ? tv.v[k] : r;
+    return r;
+}
+template <int N> MM_DEV mm_tup<N> mm_tv_set(int i, mm_tup<N> tv, float v) {
+    i = i < 0 ? 0 : (i >= N ? N - 1 : i);
+#pragma unroll
+    for (int k = 0; k < N; ++k) tv.v[k] = i == k ? v : tv.v[k];
+    return tv;
+}
 
 MM_DEV mm_tup<4> mm_tuple_from_color(color_t c) {
     mm_tup<4> t;

@@ -72,7 +72,7 @@ static void generate_closure_kernels(mmhip_filter *f, const KernelOptions &ko) {
     f->closures.clear();
     for (auto &sub : f->code->closure_renders) {
         mmhip_closure_kernel ck;
-        ck.ks = generate_hip(*sub, ko);
+        ck.ks = generate_hip(*sub, ko, f->code.get());
         if (!ck.ks.natives.empty())
             throw CompileError("a filter closure that is rendered for a native filter calls native filters itself: not supported");
         f->closures.push_back(std::move(ck));
@@ -85,18 +85,7 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
         parse_module(f->module, source);
         f->source = source;
         if (opts) f->opts = *opts;
-        try {
-            f->code = lower_filter(f->module, f->module.main, consts);
-        } catch (const CompileError &e) {
-            if (!e.needs_constants) throw;
-            // recursion controlled by user values: no generic kernel exists, every value set
-            // gets its own (active_filter); the filter is usable for invoke/set/render
-            f->deferred = true;
-            f->deferred_reason = e.what();
-            f->specialize = true;
-            f->opts.specialize_uservals = 1;
-            return f.release();
-        }
+        f->code = lower_filter(f->module, f->module.main, consts);
         f->ir_json_raw = dump_ir(*f->code);
         if (consts) specialize_constants(*f->code);
         optimize(*f->code);
@@ -106,6 +95,7 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
             optimize(*sub);
             analyze_frame_constants(*sub);
         }
+        for (auto &fn : f->code->functions) optimize(*fn);     // function bodies: no frame-constant slice, no user-value literals
         KernelOptions ko;
         if (opts) {
             ko.intersample = opts->intersample;
@@ -172,6 +162,7 @@ bool mmhip_filter_finalize(mmhip_filter *f, const KernelOptions &ko, std::string
             optimize(*sub);
             analyze_frame_constants(*sub);
         }
+        for (auto &fn : f->code->functions) optimize(*fn);
         f->kopt = ko;
         f->ir_json = dump_ir(*f->code);
         f->ks = generate_hip(*f->code, ko);
@@ -275,7 +266,6 @@ static int load_kernels(const KernelSource &ks, const std::vector<char> &code_ob
 }
 
 long mmhip_filter_jit(mmhip_filter *f, int load_module) {
-    if (f->deferred) return 0;     // kernels are built per user-value set at render time
     auto t0 = std::chrono::steady_clock::now();
     if (jit_source(f->ks, f->code_object) != 0) return -1;
     for (mmhip_closure_kernel &ck : f->closures)
@@ -890,7 +880,7 @@ static mmhip_filter *active_filter(mmhip_invocation *inv, int frame = 0, float t
     // A "use" is a render of a new frame with these values: the bands of one frame count once, so a
     // host that animates a user value (new values every frame, several calc_lines bands each) never
     // triggers a JIT per frame; an animation over t with fixed values specialises at its 2nd frame.
-    if (!f->deferred && f->spec_min_uses > 1) {
+    if (f->spec_min_uses > 1) {
         if (f->spec_uses.size() > 1024) f->spec_uses.clear();
         auto &u = f->spec_uses[key];
         if (u.count == 0 || u.frame != frame || u.t != t) {
@@ -912,7 +902,6 @@ static mmhip_filter *active_filter(mmhip_invocation *inv, int frame = 0, float t
 int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
                  int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream) {
     mmhip_filter *f = active_filter(inv, frame, t);
-    if (f->deferred) return fail(g_err.empty() ? f->deferred_reason : g_err);
     hipStream_t s = stream ? (hipStream_t)stream : inv->stream;
     if (bpp < 1 || bpp > 4) return fail("output_bpp must be 1..4");
     if (region_w <= 0 || region_h <= 0) return fail("empty region");

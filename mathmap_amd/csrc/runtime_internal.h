@@ -51,8 +51,6 @@ struct mmhip_filter {
     int spec_min_uses = 1;                    // build the variant on this many-th render with one value set
     // a filter that only compiles with its scalar user values baked in (recursion whose depth
     // they control): no generic code/kernels, every render goes through spec_cache
-    bool deferred = false;
-    std::string deferred_reason;
 };
 
 struct mmhip_invocation {

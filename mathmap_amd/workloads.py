@@ -362,7 +362,8 @@ end
 """
 
 # A recursive filter (the shape of examples/Map/IFS Functional.mm: the recursion depth is a
-# user value).  Filter calls are inlined, so the HIP backend unrolls it per depth value.
+# user value).  The recursive application is a run-time call of filter_tree; with the user values
+# baked in the lowering unrolls it instead.
 RECURSIVE = """
 filter shrink (image in, float s)
   in(xy / s)
@@ -374,6 +375,34 @@ filter tree (image in, int depth: 1-16 (4), float s: 0-1 (0.6))
   else
     in(xy) * 0.5 + shrink(tree(in, depth - 1, s), s, xy) * 0.5
   end
+end
+"""
+
+# recursion whose depth differs per pixel: it follows the image content along the walk
+RECURSIVE_DATA = """
+filter walk (image in, float budget: 0-20 (9))
+  p = in(xy);
+  if budget < 1 || p[0] < 0.25 then
+    p
+  else
+    walk(in, budget - 1 - 3 * p[1], xy * 0.9 + xy:[0.07, -0.03]) * 0.7 + p * 0.3
+  end
+end
+"""
+
+# a recursive filter that is not the main one (inlined at its two call sites, calling itself at run time),
+# with rand() inside the callee; n above MM_MAX_CALL_DEPTH exercises the cut-off
+RECURSIVE_MUTUAL = """
+filter fade (image in, int n: 0-64 (6))
+  if n < 1 then
+    in(xy)
+  else
+    fade(in, n - 1, xy * 0.95) * 0.9 + grayColor(rand(0, 0.1))
+  end
+end
+
+filter echoes (image in, int n: 0-64 (6))
+  fade(in, n, xy) + fade(in, n / 2, xy:[-x, y]) * 0.25
 end
 """
 
@@ -429,6 +458,9 @@ ALL = {
     "half_convolve": HALF_CONVOLVE,
     "curve_gradient": CURVE_GRADIENT,
     "tree_vector": TREE_VECTOR,
+    "recursive": RECURSIVE,
+    "recursive_data": RECURSIVE_DATA,
+    "recursive_mutual": RECURSIVE_MUTUAL,
 }
 
 

@@ -32,7 +32,7 @@ BUILD = os.path.join(HERE, "_build")
 CTYPES = {"int": "int", "float": "float", "complex": "float _Complex", "color": "color_t",
           "curve": "int", "gradient": "int", "image": "mmo_image"}
 
-UNSUPPORTED = {"SOLVE_POLY_2", "SOLVE_POLY_3", "TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH"}
+UNSUPPORTED = {"SOLVE_POLY_2", "SOLVE_POLY_3"}
 NOISE_OPS = {"libnoise_perlin", "libnoise_billow", "libnoise_ridged_multi", "libnoise_voronoi"}
 NOISE_LIB = os.path.join(HERE, "_ref", "libmmnoise.so")
 
@@ -67,10 +67,13 @@ def _float_literal(bits):
 
 
 class Gen:
-    def __init__(self, ir):
+    def __init__(self, ir, functions=None, in_function=False):
         self.ir = ir
         self.vars = {v["id"]: v for v in ir["vars"]}
         self.uses_noise = False
+        # filter_$name bodies this code may call ("functions" of the root dump), by filter name
+        self.functions = functions if functions is not None else ir.get("functions", [])
+        self.in_function = in_function
         self.natives = {}      # id(stmt) -> slot
         self.nnative = 0
         self._find_natives(ir["body"])
@@ -93,6 +96,8 @@ class Gen:
         v = self.vars[vid]
         if v["type"] == "tuple":
             return "mmo_tup%d" % (v["tuple_len"] or 4)
+        if v["type"] == "tree_vector":
+            return "mmo_tup%d" % v["tuple_len"]
         return CTYPES[v["type"]]
 
     def vname(self, vid, idx):
@@ -106,7 +111,7 @@ class Gen:
                 t = self.vars[vid]["type"]
                 if t == "image":
                     return "UNINITED_IMAGE"
-                if t == "tuple":
+                if t in ("tuple", "tree_vector"):
                     return "(%s){{0}}" % self.ctype(vid)
                 return "0"
             return self.vname(vid, idx)
@@ -126,7 +131,7 @@ class Gen:
             return self.prim(r["p"])
         if k == "internal":
             return r["name"]
-        if k == "tuple":
+        if k in ("tuple", "treevector"):      # backends/cc.c:268-300: float tuple[n] = { args }
             return "(mmo_tup%d){{%s}}" % (len(r["args"]), ", ".join(self.prim(a) for a in r["args"]))
         if k == "closure":
             if not r["native"]:
@@ -140,14 +145,37 @@ class Gen:
             if fn is None:
                 raise OracleUnsupported("native filter %s" % r["native"])
             return "%s(A, %d, %s)" % (fn, slot, args)
+        if k == "filtercall":
+            # backends/cc.c:221-235: the callee's arguments become its user values, then filter_$name(x, y, t)
+            names = [fn["filter"] for fn in self.functions]
+            fk = names.index(r["filter"])
+            uvs = self.functions[fk]["uservals"]
+            args = r["args"]
+            field = {1: "f", 3: "c", 6: "img"}
+            fill = " ".join("mm_ca[%d].%s = %s;" % (u["index"], field.get(u["kind"], "i"), self.prim(a)) for u, a in zip(uvs, args))
+            x, y, t = (self.prim(a) for a in args[len(uvs):])
+            depth = "mm_depth + 1" if self.in_function else "0"
+            return "({ mmo_uvarg mm_ca[%d]; %s mmo_filter_%d(A, mm_ca, %s, %s, %s, col, row, &mm_rand_ctr, %s); })" % (
+                max(1, len(uvs)), fill, fk, x, y, t, depth)
         if k == "op":
             op = r["op"]
+            if self.in_function and op.startswith("USERVAL_") and op.endswith("_ACCESS"):
+                f = {"USERVAL_FLOAT_ACCESS": "f", "USERVAL_COLOR_ACCESS": "c", "USERVAL_IMAGE_ACCESS": "img"}.get(op, "i")
+                return "(UV[%d].%s)" % (r["args"][0][1], f)
             if op in UNSUPPORTED:
                 raise OracleUnsupported("op %s" % op)
             if op in NOISE_OPS:
                 if not os.path.exists(NOISE_LIB):
                     raise OracleUnsupported("op %s (oracle/_ref/libmmnoise.so not built: no reference tree)" % op)
                 self.uses_noise = True
+            if op in ("TREE_VECTOR_NTH", "SET_TREE_VECTOR_NTH"):
+                # opmacros.h:189-190 (the index converts to the C int parameter; the vector's length is static)
+                a = r["args"]
+                n = self.vars[a[1][1]]["tuple_len"]
+                if op == "TREE_VECTOR_NTH":
+                    return "({ mmo_tup%d tv_ = %s; mmo_tv_nth((int)(%s), tv_.v, %d); })" % (n, self.prim(a[1]), self.prim(a[0]), n)
+                return "({ mmo_tup%d tv_ = %s; mmo_tv_set((int)(%s), tv_.v, %d, %s); tv_; })" % (
+                    n, self.prim(a[1]), self.prim(a[0]), n, self.prim(a[2]))
             if op == "RENDER":
                 return "mmo_render(A, %d, %s)" % (self.natives[id(stmt)], ", ".join(self.prim(a) for a in r["args"]))
             return "%s(%s)" % (op, ",".join(self.prim(a) for a in r["args"]))
@@ -242,6 +270,38 @@ class Gen:
             init = " = 0" if t in ("int", "float", "color_t") else ""
             out.append("%s%s %s%s;" % (ind, t, self.vname(*d), init))
 
+    def function_source(self, out):
+        """filter_$name of every filter called at run time (new_template.c.in:375-422: a C function per filter,
+        called through the closure).  Ordinary recursive C, as in the reference, except that depth
+        MM_MAX_CALL_DEPTH returns zeros -- the HIP path's stack bound, restated so both cut off alike."""
+        if not self.functions:
+            return
+        out.append("typedef struct { int i; float f; color_t c; mmo_image img; } mmo_uvarg;")
+        out.append("#ifndef MM_MAX_CALL_DEPTH\n#define MM_MAX_CALL_DEPTH %d\n#endif" % int(os.environ.get("MMHIP_MAX_CALL_DEPTH", "16")))
+        sig = "static mmo_tup4 mmo_filter_%d(const mmo_args *A, const mmo_uvarg *UV, float x, float y, float t, int col, int row, unsigned *mm_rand_p, int mm_depth)"
+        for k in range(len(self.functions)):
+            out.append(sig % k + ";")
+        out.append("#define mm_rand_ctr (*mm_rand_p)")
+        for k, fn in enumerate(self.functions):
+            g = Gen(fn, functions=self.functions, in_function=True)
+            defs, uses = [], set()
+            g.collect(fn["body"], False, defs, uses)
+            out.append("/* filter_%s */" % fn["filter"])
+            out.append(sig % k + " {")
+            out.append("  mmo_tup4 rt = {{0, 0, 0, 0}};")
+            out.append("  if (mm_depth >= MM_MAX_CALL_DEPTH) return rt;")
+            out.append("  const float R = A->R; const int frame = A->frame;")
+            out.append("  const int __canvasPixelW = A->img_width, __canvasPixelH = A->img_height;")
+            out.append("  const int __renderPixelW = A->render_width, __renderPixelH = A->render_height;")
+            out.append("  (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;")
+            g.decls(defs, "  ", out)
+            g.stmts(fn["body"], False, "  ", out)
+            for i, r in enumerate(fn["result"]):
+                out.append("  rt.v[%d] = %s;" % (i, g.prim(["v", r[0], r[1]])))
+            out.append("  return rt;\n}")
+            self.uses_noise = self.uses_noise or g.uses_noise
+        out.append("#undef mm_rand_ctr\n")
+
     def source(self):
         ir = self.ir
         pro_defs, pro_uses, pix_defs, pix_uses = [], set(), [], set()
@@ -258,7 +318,15 @@ class Gen:
                "float libnoise_perlin(int, float, float, float, float, float);",
                "float libnoise_billow(int, float, float, float, float, float);",
                "float libnoise_ridged_multi(int, float, float, float, float);",
-               "float libnoise_voronoi(float, float, float, float);", "", "typedef struct {"]
+               "float libnoise_voronoi(float, float, float, float);", ""]
+        lens = set()
+        for code in [ir] + list(self.functions):
+            for v in code["vars"]:
+                if v["type"] in ("tuple", "tree_vector") and v["tuple_len"] not in (0, 2, 3, 4, 9):
+                    lens.add(v["tuple_len"])
+        for n in sorted(lens):      # mm_oracle.h has the lengths the builtins use
+            out.append("typedef struct { float v[%d]; } mmo_tup%d;" % (n, n))
+        out.append("typedef struct {")
         for d in transfers:
             out.append("  %s %s;" % (self.ctype(d[0]), self.vname(*d)))
         out.append("  int unused_;")
@@ -272,10 +340,13 @@ class Gen:
 
 int mmo_xy_size(void) { return (int)sizeof(xy_vars_t); }
 int mmo_num_natives(void) { return %d; }
-
-void mmo_init_frame(const mmo_args *A, void *xyv) {
+""" % self.nnative)
+        self.function_source(out)
+        out.append("""void mmo_init_frame(const mmo_args *A, void *xyv) {
   xy_vars_t *xy_vars = (xy_vars_t *)xyv;
-  MMO_INTERNALS""" % self.nnative)
+  MMO_INTERNALS""")
+        if self.functions:
+            out.append("  const int col = 0, row = 0; unsigned mm_rand_ctr = 0; (void)col; (void)row; (void)mm_rand_ctr;")
         self.decls(pro_defs, "  ", out)
         self.stmts(ir["body"], True, "  ", out)
         for d in transfers:
@@ -445,7 +516,8 @@ class CpuFilter:
                     pass
         # closure images handed to native filters: each is rendered by its own code (render_image's closure
         # branch launches the closure's calc_lines), the IR dump carries that code under "closure_renders"
-        self.subs = [CpuFilter(sub, extra_cflags) for sub in self.ir.get("closure_renders", [])]
+        self.subs = [CpuFilter(dict(sub, functions=self.ir.get("functions", [])), extra_cflags)
+                     for sub in self.ir.get("closure_renders", [])]
         self.lib = C.CDLL(so)
         self.lib.mmo_xy_size.restype = C.c_int
         self.lib.mmo_init_frame.argtypes = [C.POINTER(_Args), C.c_void_p]

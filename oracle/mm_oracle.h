@@ -135,6 +135,9 @@ typedef struct {
 #define CALC_VIRTUAL_Y(pxl, size, sampl_off) ((-(pxl) + ((size)-1) / 2.0 - (sampl_off)) / (((size)-1) / 2.0))
 
 #define TUPLE_NTH(t, n) ((t).v[(n)])
+/* tree vectors (tree_vectors.c:89-150): a float array of static length, indices clamped, a write makes a new vector */
+static inline float mmo_tv_nth(int i, const float *v, int n) { return v[i < 0 ? 0 : (i >= n ? n - 1 : i)]; }
+static inline void mmo_tv_set(int i, float *v, int n, float x) { v[i < 0 ? 0 : (i >= n ? n - 1 : i)] = x; }
 
 #define USERVAL_INT_ACCESS(n) (A->uservals[(n)].i)
 #define USERVAL_FLOAT_ACCESS(n) (A->uservals[(n)].f)

@@ -30,8 +30,6 @@ def main():
         stem = os.path.splitext(golden)[0]
         try:
             flt = mm.Filter(open(os.path.join(REF, script)).read())
-            if flt.needs_constants:      # recursive filter: the variant for this case's user values
-                flt = flt.specialized(uv)
             flt.jit(load=False)      # must at least compile for gfx950
         except mm.MathMapError as e:
             print("skip %-40s %s" % (stem, str(e).splitlines()[0][:70]))
@@ -57,8 +55,6 @@ def make_example_fixtures():
         rel = os.path.relpath(path, "/root/reference/examples")
         stem = rel[:-3].replace("/", "__").replace(" ", "_")
         flt = mm.Filter(open(path, errors="replace").read())
-        if flt.needs_constants:
-            flt = flt.specialized()
         with open(os.path.join(out, stem + ".json.gz"), "wb") as raw:
             with gzip.GzipFile(fileobj=raw, mode="wb", compresslevel=9, mtime=0, filename="") as f:
                 f.write(flt.ir_json_raw.encode())

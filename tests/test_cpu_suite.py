@@ -18,8 +18,6 @@ from tests.conftest import REFERENCE, ROOT, load_png_rgb
 
 def oracle_render(src, uv=None, image=None, w=256, h=256, t=0.0, intersample=True):
     flt = mm.Filter(src)
-    if flt.needs_constants:      # recursion unrolled per user-value set (lower.cpp gen_filter)
-        flt = flt.specialized(uv)
     images = {"in": image} if image is not None else {}
     return CpuFilter(flt.ir_json_raw).render(w, h, uservals=uv, images=images, t=t, intersample=intersample)
 
@@ -147,8 +145,6 @@ def test_ir_fixtures_equal_a_fresh_compile():
     for m in man:
         script, golden, uv, needs = by_golden[m["golden"]]
         flt = mm.Filter(open(os.path.join(REFERENCE, "tests", script)).read())
-        if flt.needs_constants:
-            flt = flt.specialized(uv)
         have = gzip.open(os.path.join(ROOT, "tests", "golden", "ir", m["ir"]), "rt").read()
         n += 1
         if have != flt.ir_json_raw:
@@ -157,8 +153,6 @@ def test_ir_fixtures_equal_a_fresh_compile():
         rel = os.path.relpath(path, os.path.join(REFERENCE, "examples"))
         stem = rel[:-3].replace("/", "__").replace(" ", "_")
         flt = mm.Filter(open(path, errors="replace").read())
-        if flt.needs_constants:
-            flt = flt.specialized()
         have = gzip.open(os.path.join(ROOT, "tests", "golden", "ir_examples", stem + ".json.gz"), "rt").read()
         n += 1
         if have != flt.ir_json_raw:
@@ -214,28 +208,42 @@ def test_userval_specialisation_preserves_results_on_cpu(name, uv):
     assert np.array_equal(a, b), np.abs(a.astype(int) - b.astype(int)).max()
 
 
-def test_recursive_filter_unrolls_per_user_value_set():
-    """A recursive filter has no generic kernel (needs_constants); with the depth baked in the
-    recursion is unrolled while lowering.  depth = 1 must equal the plain fetch, and an
-    unbounded recursion is a compile error, not a hang."""
+def test_recursive_filter_calls_at_run_time_and_unrolls_with_literals():
+    """A recursive application is a run-time call of filter_$name (compiler.c:2165-2222 RHS_FILTER,
+    backends/cc.c:221-235): the IR carries the callee's body under "functions" and one generic kernel serves
+    every depth.  With the user values baked in the recursion is unrolled while lowering instead; the two
+    forms must agree byte for byte.  depth = 1 equals the plain fetch; a recursion that never ends is cut
+    off at MM_MAX_CALL_DEPTH (zeros) in the oracle exactly as in the kernel."""
     flt = mm.Filter(W.RECURSIVE)
-    assert flt.needs_constants and [u["name"] for u in flt.uservals] == ["in", "depth", "s"]
+    assert [u["name"] for u in flt.uservals] == ["in", "depth", "s"]
+    raw = json.loads(flt.ir_json_raw)
+    assert [fn["filter"] for fn in raw["functions"]] == ["tree"] and '"filtercall"' in flt.ir_json_raw
+    assert "mm_filter_0<0>" in flt.kernel_source and "mm_filter_0<MM_D + 1>" in flt.kernel_source
     img = W.synthetic_image(64, 48, seed=2)
-    one = CpuFilter(flt.specialized({"depth": 1}).ir_json_raw).render(64, 48, images={"in": img})
+    generic = CpuFilter(flt.ir_json_raw)
     ident = CpuFilter(mm.Filter(W.IDENT).ir_json_raw).render(64, 48, images={"in": img})
-    assert np.array_equal(one, ident)
-    sizes = [len(flt.specialized({"depth": d}).ir_json) for d in (1, 2, 4)]
-    assert sizes[0] < sizes[1] < sizes[2]
-    with pytest.raises(mm.MathMapError) as e:
-        mm.Filter("filter f (image in, int d: 1-9 (3)) f(in, d, xy) end", constants={"d": 3})
-    assert "recursi" in str(e.value)
+    assert np.array_equal(generic.render(64, 48, uservals={"depth": 1}, images={"in": img}), ident)
+    sizes = []
+    for d in (1, 2, 4, 7):
+        uv = {"depth": d, "s": 0.7}
+        sp = flt.specialized(uv)
+        assert "functions" not in json.loads(sp.ir_json_raw) and "mm_filter_" not in sp.kernel_source
+        sizes.append(len(sp.ir_json))
+        a = generic.render(64, 48, uservals=uv, images={"in": img})
+        b = CpuFilter(sp.ir_json_raw).render(64, 48, uservals=uv, images={"in": img})
+        assert np.array_equal(a, b), d
+    assert sizes[0] < sizes[1] < sizes[2] < sizes[3]
+    # no literal ends this recursion: even with d baked in it stays a call, and the call depth bound ends it
+    endless = mm.Filter("filter f (image in, int d: 1-9 (3)) f(in, d, xy) end", constants={"d": 3})
+    assert '"filtercall"' in endless.ir_json_raw
+    out = CpuFilter(endless.ir_json_raw).render(16, 8, images={"in": img})
+    assert not out[..., :3].any()
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present")
 def test_every_reference_example_compiles_for_gfx950():
     """All 189 filters under the reference's examples/ go through the front-end, the lowering, the
-    kernel generator and hiprtc (--offload-arch=gfx950); recursive ones with their default user
-    values.  (Code objects are cached on disk, so only the first run pays the ~90 s.)"""
+    kernel generator and hiprtc (--offload-arch=gfx950).  (Code objects are cached on disk, so only the first run pays the ~90 s.)"""
     import glob
     files = sorted(glob.glob(os.path.join(REFERENCE, "examples", "**", "*.mm"), recursive=True))
     assert len(files) == 189
@@ -243,7 +251,7 @@ def test_every_reference_example_compiles_for_gfx950():
     for f in files:
         try:
             flt = mm.Filter(open(f, errors="replace").read())
-            (flt.specialized() if flt.needs_constants else flt).jit()
+            flt.jit()
         except mm.MathMapError as e:
             bad[os.path.relpath(f, REFERENCE)] = str(e).splitlines()[0][:120]
     assert not bad, bad

@@ -370,7 +370,11 @@ def test_mandelbrot_8192_stripe_property():
 
 
 @pytest.mark.parametrize("name,bands", [("mandelbrot", 1), ("pond", 3), ("droste", 2), ("gaussian_blur", 1),
-                                        ("closure_arg", 2), ("curve_gradient", 2)])
+                                        ("closure_arg", 2), ("curve_gradient", 2),
+                                        # RHS_FILTER statements + the callee's filter_code (run-time filter_$name calls)
+                                        ("recursive", 2), ("recursive_data", 1), ("recursive_mutual", 3),
+                                        # TYPE_TREE_VECTOR values, RHS_TREE_VECTOR, TREE_VECTOR_NTH / SET_TREE_VECTOR_NTH
+                                        ("tree_vector", 2)])
 def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     """gen_and_load_hip_code + the returned mathfuncs, driven with reference-layout
     structures (include/mathmap_abi.h) the way mathmap_common.c drives the cc backend,
@@ -831,24 +835,51 @@ def test_convolve_with_impulse_is_identity_at_2048():
     assert np.array_equal(inv.render(t=0.5), got)
 
 
-def test_recursive_filter_renders_per_depth():
-    """Deferred (needs_constants) filter through the normal invoke/set/render path: each depth
-    value builds its own kernel; compared with the oracle on the same unrolled IR."""
+def test_recursive_filter_calls_filter_functions_on_the_gpu():
+    """Run-time filter_$name calls (RHS_FILTER): one generic kernel, the recursion depth is a user value read
+    per render.  Bit-exact against the oracle's recursive C functions, and against the kernel with the
+    depth baked in (recursion unrolled while lowering, no calls)."""
     w, h = 96, 64
     img = W.synthetic_image(w, h, seed=2)
     flt = mm.Filter(W.RECURSIVE)
-    assert flt.needs_constants
+    assert "mm_filter_0<0>" in flt.kernel_source
+    cpu = CpuFilter(flt.ir_json_raw)
     inv = flt.invoke(w, h)
     inv.set_image("in", img)
     outs = []
-    for depth in (1, 3, 5):
+    for depth in (1, 3, 5, 16):
         inv.set("depth", depth)
         got = inv.render()
-        want = CpuFilter(flt.specialized({"depth": depth}).ir_json_raw).render(w, h, images={"in": img})
-        mx, nd, n1 = stats(got, want)
-        assert mx <= 1, (depth, mx, nd, n1)
+        want = cpu.render(w, h, uservals={"depth": depth}, images={"in": img})
+        assert np.array_equal(got, want), (depth, stats(got, want))
+        if depth <= 5:
+            sp = flt.specialized({"depth": depth})
+            assert "mm_filter_" not in sp.kernel_source
+            si = sp.invoke(w, h)
+            si.set_image("in", img)
+            si.set("depth", depth)
+            assert np.array_equal(si.render(), got), depth
         outs.append(got)
     assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[1], outs[2])
+
+
+def test_data_dependent_recursion_on_the_gpu():
+    """The recursion depth differs per pixel (it follows the image content and the position), which no
+    lowering-time unrolling could serve; mutual recursion between two filters; RAND inside the callee keeps the
+    pixel's call counter.  Bit-exact against the oracle, including the cut-off at MM_MAX_CALL_DEPTH."""
+    w, h = 128, 96
+    img = W.synthetic_image(w, h, seed=5)
+    cases = [(W.RECURSIVE_DATA, {}), (W.RECURSIVE_MUTUAL, {"n": 6}), (W.RECURSIVE_MUTUAL, {"n": 40})]
+    for src, uv in cases:
+        flt = mm.Filter(src)
+        inv = flt.invoke(w, h)
+        inv.set_image("in", img)
+        for k, v in uv.items():
+            inv.set(k, v)
+        got = inv.render(t=0.3)
+        want = CpuFilter(flt.ir_json_raw).render(w, h, uservals=uv, images={"in": img}, t=0.3)
+        assert np.array_equal(got, want), (uv, stats(got, want))
+        assert got[..., :3].any()
 
 
 @pytest.mark.parametrize("seed", range(80))
