@@ -235,6 +235,9 @@ struct Generator {
                         return "MM_SQRT_LESS_POW2(" + prim(d->rhs.args[0], sl) + ", " + float_literal((float)(k * k)) + "f)";
                     }
                 }
+                if (sl == PIXEL && hot_mode && stmt == fetched_result)
+                    return "mm_tuple_of_sums(mm_rs[mm_u] = mm_orig_val_sums_hot(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " +
+                           prim(r.args[2], sl) + ", " + vname(r.args[2].value) + "_desc, mm_bad))";
                 if (sl == PIXEL && hot_mode && hot_sites.count(stmt))
                     return "mm_orig_val_hot(A, " + prim(r.args[0], sl) + ", " + prim(r.args[1], sl) + ", " + prim(r.args[2], sl) +
                            ", " + vname(r.args[2].value) + "_desc, mm_bad)";
@@ -352,6 +355,26 @@ struct Generator {
     std::set<const Value *> preloaded_desc;   // image values whose descriptor is loaded before the pixel loop
     std::set<const Stmt *> hot_sites;         // ORIG_VAL statements eligible for mm_orig_val_hot
     bool hot_mode = false;
+    // The hot fetch whose four channels are the filter's result, unchanged (the last statement of every pure
+    // distortion: `in(f(xy))`): the hot loop then keeps the fetch's rounded byte sums and stores them directly
+    // (mm_store_fetched_pixel) instead of dividing by 255, clamping and multiplying by 255 again.
+    const Stmt *fetched_result = nullptr;
+    const Stmt *find_fetched_result() const {
+        if (!opt.intersample || getenv("MMHIP_NO_FETCHED_RESULT")) return nullptr;
+        const Stmt *fetch = nullptr;
+        for (int i = 0; i < 4; ++i) {
+            const Value *v = code.result[i];
+            const Stmt *d = v ? v->def : nullptr;
+            // copies between the TUPLE_NTH and the result are gone after copy propagation
+            if (!d || d->kind != Stmt::Assign || d->parent || !d->in_pixel || d->rhs.kind != Rhs::Op || strcmp(d->rhs.op->cname, "TUPLE_NTH") ||
+                d->rhs.args[0].kind != Primary::Val || d->rhs.args[1].kind != Primary::IntConst || d->rhs.args[1].i != i)
+                return nullptr;
+            const Stmt *f = d->rhs.args[0].value->def;
+            if (!f || f->parent || !hot_sites.count(f) || (fetch && f != fetch)) return nullptr;
+            fetch = f;
+        }
+        return fetch;
+    }
 
     // ORIG_VALs of the pixel slice whose image descriptor is preloaded and whose frame
     // argument is a literal or a frame constant: their "bound drawable, valid frame" test can
@@ -396,14 +419,24 @@ struct Generator {
 
     // Filters that fetch pixels are bound by memory latency with one pixel in flight per
     // work-item (measured: a nearest fetch cost 0.25 ms at 8192^2 against 0.06 ms for the
-    // store); evaluating two pixels back to back doubles the loads in flight.  Large bodies
-    // are left alone: twice the code and registers costs more occupancy than it gains.
+    // store); evaluating several pixels back to back multiplies the loads in flight.  Measured at 8192^2
+    // (tools/ab_unroll.sh, profiles/r02_ab_unroll.txt): Ident 0.233 / 0.204 / 0.205 ms and Pond 0.705 / 0.673 /
+    // 0.752 ms for 2 / 4 / 8 pixels.  Large bodies are left alone: more code and registers cost more
+    // occupancy than the overlap gains.
     int auto_unroll() const {
         if (const char *e = getenv("MMHIP_UNROLL")) { int u = atoi(e); if (u >= 1 && u <= 8) return u; }
         int stmts = 0, fetches = 0;
         pixel_stats(code.body, stmts, fetches);
         if (fetches == 0) return 1;
-        return stmts <= 400 ? 2 : 1;
+        return stmts <= 64 ? 4 : stmts <= 400 ? 2 : 1;
+    }
+    // Columns of a workgroup's 256 work-items.  16 x 16 keeps the gathers of a distortion local in both directions;
+    // a body that is little more than its fetch (a copy, a scale, a flip) streams rows, and a wave that covers
+    // 64 pixels of one row reads and writes whole cache lines (same A/B: Ident 0.204 -> 0.187 ms, Pond 0.673 -> 0.684).
+    int auto_tile_w() const {
+        int stmts = 0, fetches = 0;
+        pixel_stats(code.body, stmts, fetches);
+        return fetches >= 1 && stmts <= 12 ? 64 : 16;
     }
 
     void find_natives(Block &b) {
@@ -1018,7 +1051,8 @@ struct Generator {
 
     void emit_source() {
         int tw = opt.tile_w;
-        if (tw != 8 && tw != 16 && tw != 32 && tw != 64 && tw != 128 && tw != 256) tw = 16;
+        if (const char *e = getenv("MMHIP_TILE_W")) tw = atoi(e);      // experiments (tools/ab_unroll.sh)
+        if (tw != 8 && tw != 16 && tw != 32 && tw != 64 && tw != 128 && tw != 256) tw = auto_tile_w();
         ks.tile_w = tw;
         ks.tile_h = 256 / tw;
         out << "#define MM_INTERSAMPLE " << opt.intersample << "\n";
@@ -1182,13 +1216,22 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                     << I << "  mm_store_pixel(A, row_b, col, mm_rb);\n" << I << "}\n";
                 return;
             }
+            const bool fetched = hot && fetched_result;
+            // The row coordinates of an iteration are loaded during the one before it (those of the first before the
+            // loop): a work-item's iterations are a serial chain, and the table load in front of each would add one
+            // memory round trip per iteration to it.  (Rows past the end read the last row's entry.)
+            out << I << "float mm_y[MM_UNROLL];\n"
+                << "#pragma unroll\n" << I << "for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
+                << I << "  const int rl_raw = row0 + (mm_p + mm_u) * MM_TILE_H;\n"
+                << I << "  mm_y[mm_u] = A.ytab[rl_raw < A.num_rows ? rl_raw : A.num_rows - 1];\n"
+                << I << "}\n";
             out << "#pragma unroll 1\n" << I << "for (; mm_p < A.ppt; mm_p += MM_UNROLL) {\n"
-                << I << "  mm_tup<4> mm_rt[MM_UNROLL];\n"
-                << I << "  float mm_y[MM_UNROLL];\n"
+                << I << (fetched ? "  mm_bilinear mm_rs[MM_UNROLL];\n" : "  mm_tup<4> mm_rt[MM_UNROLL];\n")
+                << I << "  float mm_yn[MM_UNROLL];\n"
                 << I << "  bool mm_bad = false;   // a hot fetch met a NaN / inf / > 2^31 px coordinate\n"
-                << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {   // all row coordinates first: one wait\n"
-                << I << "    const int rl_raw = row0 + (mm_p + mm_u) * MM_TILE_H;\n"
-                << I << "    mm_y[mm_u] = A.ytab[rl_raw < A.num_rows ? rl_raw : A.num_rows - 1];\n"
+                << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
+                << I << "    const int rl_raw = row0 + (mm_p + MM_UNROLL + mm_u) * MM_TILE_H;\n"
+                << I << "    mm_yn[mm_u] = A.ytab[rl_raw < A.num_rows ? rl_raw : A.num_rows - 1];\n"
                 << I << "  }\n"
                 << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) {\n"
                 << I << "    const float y = mm_y[mm_u];    // CALC_VIRTUAL_Y(first_row + rl, ...), once per row by the prologue\n"
@@ -1198,7 +1241,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                 << I << "    (void)y; (void)rl; (void)mm_rand_ctr;\n";
             decls(pix_defs, (I + "    ").c_str());
             stmts(code.body, PIXEL, (I + "    ").c_str());
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4 && !fetched; ++i)
                 out << I << "    mm_rt[mm_u].v[" << i << "] = " << prim(Primary::V(code.result[i]), PIXEL) << ";\n";
             out << I << "  }\n";
             if (hot)
@@ -1208,7 +1251,11 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                 << I << "    // same bytes, and keeps the pixel bodies free of a store guard the compiler would\n"
                 << I << "    // otherwise sink them (and their loads) into\n"
                 << I << "    const int rl_raw = row0 + (mm_p + mm_u) * MM_TILE_H;\n"
-                << I << "    mm_store_pixel(A, rl_raw < A.num_rows ? rl_raw : A.num_rows - 1, col, mm_rt[mm_u]);\n" << I << "  }\n" << I << "}\n";
+                << I << (fetched ? "    mm_store_fetched_pixel(A, rl_raw < A.num_rows ? rl_raw : A.num_rows - 1, col, mm_rs[mm_u]);\n"
+                                 : "    mm_store_pixel(A, rl_raw < A.num_rows ? rl_raw : A.num_rows - 1, col, mm_rt[mm_u]);\n")
+                << I << "  }\n"
+                << "#pragma unroll\n" << I << "  for (int mm_u = 0; mm_u < MM_UNROLL; ++mm_u) mm_y[mm_u] = mm_yn[mm_u];\n"
+                << I << "}\n";
         };
         // Hot variant: when every fetch through a preloaded descriptor reads a bound drawable
         // at a valid, frame-constant frame number (true for every ordinary render), those
@@ -1225,7 +1272,9 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
             for (const std::string &c : hot_conds) out << "  mm_hot = mm_hot && " << c << ";\n";
             out << "  if (mm_hot) {\n";
             hot_mode = true;
+            fetched_result = find_fetched_result();
             emit_loop("    ", true);
+            fetched_result = nullptr;
             hot_mode = false;
             out << "  }\n";
         } else {

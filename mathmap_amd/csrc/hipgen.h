@@ -12,7 +12,7 @@ struct KernelOptions {
     int intersample = 1;      // bilinear input fetch (CLI flag -i)
     int supersampling = 0;
     int edge_x = 0, edge_y = 0;
-    int tile_w = 16;          // pixels per workgroup row; tile_h = 256 / tile_w
+    int tile_w = 0;           // pixels per workgroup row (0: chosen from the body, auto_tile_w); tile_h = 256 / tile_w
     int unroll = 0;           // pixels evaluated back to back per work-item step; 0 = choose (hipgen.cpp auto_unroll)
     bool hoist = true;        // evaluate frame-constant code once per frame in a prologue kernel
     bool fast_math_exact = true;   // use f32 paths only where bit-identical to the double path

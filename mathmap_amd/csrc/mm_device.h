@@ -613,20 +613,45 @@ MM_DEV mm_f2 mm_bytes_to_unit(mm_f2 k) {
 // get_orig_val_intersample_pixel + TUPLE_FROM_COLOR for a hot image, fused: same operations
 // in the same order per channel (builtins.c:202-250), two channels per packed instruction;
 // the rounded channel value stays a float ((color_t)rintf(v) & 0xff is rintf(v) for the
-// [0, 255.5) a convex combination of bytes lies in; v_med3 keeps wild coordinates in range).
+// [0, 255.5) a convex combination of bytes lies in).
 // `bad` is raised for a coordinate that is NaN / infinite / beyond +-2^31 pixels: the caller then
 // discards this result and re-evaluates the pixel through the generic path (mm_x86_byte above).
-MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc &d, float x, float y, bool &bad) {
+struct mm_bilinear { mm_f2 rg, ba; };      // the four rounded channel sums: integer-valued floats in [0, 255]
+
+MM_DEV mm_bilinear mm_intersample_sums_hot(const mm_args &A, const mm_image_desc &d, float x, float y, bool &bad) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
-    const int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;
-    const int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
-    bad = bad || x1 == (int)0x80000000 || y1 == (int)0x80000000;
+    // A coordinate the reference's (int) conversion turns into INT_MIN (NaN, infinite, beyond +-2^31 px) raises
+    // `bad`: the caller discards this result and re-evaluates the pixel on the generic path.  Such a lane goes on
+    // with coordinate 0, so that whatever the pixel body does with the discarded value stays tame: every lane's
+    // weights are in [0, 1] and its sums in [0, 255.001).
+    const bool ok_x = fabsf(x) < 2147483648.0f, ok_y = fabsf(y) < 2147483648.0f;
+    bad = bad || !ok_x || !ok_y;
+    x = ok_x ? x : 0.0f;
+    y = ok_y ? y : 0.0f;
+    const int x1 = (int)floorf(x), x2 = x1 + 1;
+    const int y1 = (int)floorf(y), y2 = y1 + 1;
     const float x2fact = x - x1, y2fact = y - y1;
     const float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
     const float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
-    const color_t p1 = mm_get_pixel(A, d, x1, y1), p2 = mm_get_pixel(A, d, x1, y2);
-    const color_t p3 = mm_get_pixel(A, d, x2, y1), p4 = mm_get_pixel(A, d, x2, y2);
+    color_t p1, p2, p3, p4;
+    // All four taps of every lane inside the image -- the case of nearly every wave: no clamping, no edge
+    // colours, and the taps are two 8-byte loads (x1, x2 are neighbours in a row; global loads only need dword
+    // alignment) whose addresses cost three instructions.  The branch is wave-uniform.
+    // (one ballot per comparison: each is the v_cmp's lane mask itself, the OR is scalar)
+    const bool all_inside = (__builtin_amdgcn_ballot_w64((unsigned)x1 >= (unsigned)(d.w - 1)) |
+                             __builtin_amdgcn_ballot_w64((unsigned)y1 >= (unsigned)(d.h - 1))) == 0;
+    if (__builtin_expect(all_inside, 1)) {
+        typedef unsigned mm_u2 __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(1))) mm_u2 *mm_gpix2;
+        const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)d.data;
+        const unsigned boff = (__umul24((unsigned)y1, (unsigned)d.w) + (unsigned)x1) << 2;
+        const mm_u2 top = *(mm_gpix2)(base + boff), bot = *(mm_gpix2)(base + (boff + ((unsigned)d.w << 2)));
+        p1 = top.x; p3 = top.y; p2 = bot.x; p4 = bot.y;
+    } else {
+        p1 = mm_get_pixel(A, d, x1, y1); p2 = mm_get_pixel(A, d, x1, y2);
+        p3 = mm_get_pixel(A, d, x2, y1); p4 = mm_get_pixel(A, d, x2, y2);
+    }
     mm_f2 rg = mm_f2{(float)RED(p1), (float)GREEN(p1)} * p1fact, ba = mm_f2{(float)BLUE(p1), (float)ALPHA(p1)} * p1fact;
     rg = rg + mm_f2{(float)RED(p2), (float)GREEN(p2)} * p2fact;
     ba = ba + mm_f2{(float)BLUE(p2), (float)ALPHA(p2)} * p2fact;
@@ -634,15 +659,34 @@ MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc 
     ba = ba + mm_f2{(float)BLUE(p3), (float)ALPHA(p3)} * p3fact;
     rg = rg + mm_f2{(float)RED(p4), (float)GREEN(p4)} * p4fact;
     ba = ba + mm_f2{(float)BLUE(p4), (float)ALPHA(p4)} * p4fact;
-    rg = mm_f2{__builtin_amdgcn_fmed3f(rintf(rg.x), 0.0f, 255.0f), __builtin_amdgcn_fmed3f(rintf(rg.y), 0.0f, 255.0f)};
-    ba = mm_f2{__builtin_amdgcn_fmed3f(rintf(ba.x), 0.0f, 255.0f), __builtin_amdgcn_fmed3f(rintf(ba.y), 0.0f, 255.0f)};
-    rg = mm_bytes_to_unit(rg);
-    ba = mm_bytes_to_unit(ba);
+    mm_bilinear r;      // rintf of a sum in [0, 255.001) is a byte: (color_t)rintf(v) & 0xff changes nothing
+    r.rg = mm_f2{rintf(rg.x), rintf(rg.y)};
+    r.ba = mm_f2{rintf(ba.x), rintf(ba.y)};
+    return r;
+}
+
+MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc &d, float x, float y, bool &bad) {
+    const mm_bilinear s = mm_intersample_sums_hot(A, d, x, y, bad);
+    const mm_f2 rg = mm_bytes_to_unit(s.rg), ba = mm_bytes_to_unit(s.ba);
     mm_tup<4> t;
     t.v[0] = rg.x; t.v[1] = rg.y; t.v[2] = ba.x; t.v[3] = ba.y;
     return t;
 }
 
+#if MM_INTERSAMPLE
+// the fetch of a pixel that goes to the output unchanged: the rounded sums are kept for mm_store_fetched_pixel
+MM_DEV mm_bilinear mm_orig_val_sums_hot(const mm_args &A, float x, float y, mm_image img, const mm_image_desc &d, bool &bad) {
+    x *= img.resized ? img.xf : 1.0f;
+    y *= img.resized ? img.yf : 1.0f;
+    return mm_intersample_sums_hot(A, d, x, y, bad);
+}
+MM_DEV mm_tup<4> mm_tuple_of_sums(const mm_bilinear &s) {
+    const mm_f2 rg = mm_bytes_to_unit(s.rg), ba = mm_bytes_to_unit(s.ba);
+    mm_tup<4> t;
+    t.v[0] = rg.x; t.v[1] = rg.y; t.v[2] = ba.x; t.v[3] = ba.y;
+    return t;
+}
+#endif
 MM_DEV mm_tup<4> mm_orig_val_hot(const mm_args &A, float x, float y, mm_image img, const mm_image_desc &d, bool &bad) {
     x *= img.resized ? img.xf : 1.0f;
     y *= img.resized ? img.yf : 1.0f;
@@ -666,6 +710,40 @@ MM_DEV mm_tup<4> mm_orig_val(const mm_args &A, float x, float y, mm_image img, f
 // after the multiply and the conversion to a byte.
 MM_DEV float mm_clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
+// Four unit-range channels to RGBA8 bytes (R in the lowest byte = first in memory).  new_template.c.in:279-293
+// computes (unsigned char)(c * 255.0) with c = CLAMP01(v): the double product of a float and 255 is exact and
+// the conversion truncates, so the byte is floor(255 c).  One f32 fma under round-toward-zero gives the same:
+// RTZ(255 c + 2^23) has integer spacing, i.e. it is 2^23 + floor(255 c), and that integer sits in the low
+// mantissa bits -- no f64 conversions and products (half rate), no float-to-int conversion.  The mode change is
+// inside one asm statement together with the instructions that need it, so nothing can move across it.
+MM_DEV unsigned mm_pack_rgba8(float r, float g, float b, float a) {
+    r = mm_clamp01(r); g = mm_clamp01(g); b = mm_clamp01(b); a = mm_clamp01(a);
+    unsigned ur, ug, ub, ua;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_fma_f32 %0, %4, %8, %9\n\t"
+                 "v_fma_f32 %1, %5, %8, %9\n\t"
+                 "v_fma_f32 %2, %6, %8, %9\n\t"
+                 "v_fma_f32 %3, %7, %8, %9\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(ur), "=&v"(ug), "=&v"(ub), "=&v"(ua)
+                 : "v"(r), "v"(g), "v"(b), "v"(a), "s"(255.0f), "v"(8388608.0f));
+    const unsigned lo = __builtin_amdgcn_perm(ug, ur, 0x0c0c0400u);      // r | g << 8
+    const unsigned hi = __builtin_amdgcn_perm(ua, ub, 0x0c0c0400u);      // b | a << 8
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+// the same bytes from the rounded sums of a bilinear fetch (integer-valued floats k in [0, 255]) whose unit
+// values k / 255 go to the output unchanged: floor(255 * RN(k / 255)) is k for all 256 values (enumerated in
+// tests/test_cpu_suite.py), so the division, the clamp and the product cancel
+MM_DEV unsigned mm_float_bits(float f) { union { float f; unsigned u; } c; c.f = f; return c.u; }
+MM_DEV unsigned mm_pack_bytes(const mm_bilinear &s) {
+    const mm_f2 rg = s.rg + 8388608.0f, ba = s.ba + 8388608.0f;      // the integer lands in the low mantissa bits
+    // (by value through mm_float_bits: __builtin_bit_cast of a vector element reads element 0 with this compiler)
+    const float r = rg.x, g = rg.y, b = ba.x, a = ba.y;
+    const unsigned lo = __builtin_amdgcn_perm(mm_float_bits(g), mm_float_bits(r), 0x0c0c0400u);
+    const unsigned hi = __builtin_amdgcn_perm(mm_float_bits(a), mm_float_bits(b), 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 MM_DEV void mm_store_pixel(const mm_args &A, int row_in_launch, int col, const mm_tup<4> &rt) {
     if (A.floatmap) {
         float4 *o = (float4 *)A.out + (long)row_in_launch * A.frame_render_width + col;
@@ -674,14 +752,11 @@ MM_DEV void mm_store_pixel(const mm_args &A, int row_in_launch, int col, const m
     }
     unsigned char *p = (unsigned char *)A.out + (long)row_in_launch * A.row_stride + (long)col * A.output_bpp;
     const int bpp = A.output_bpp;
-    // new_template.c.in:279-293: the products are double, the conversion to a byte truncates
     if (bpp == 4) {
-        // one aligned 32-bit store: bytes R,G,B,A in memory order
-        const unsigned r = (unsigned char)(mm_clamp01(rt.v[0]) * 255.0), g = (unsigned char)(mm_clamp01(rt.v[1]) * 255.0);
-        const unsigned b = (unsigned char)(mm_clamp01(rt.v[2]) * 255.0), a = (unsigned char)(mm_clamp01(rt.v[3]) * 255.0);
-        *(unsigned *)p = r | (g << 8) | (b << 16) | (a << 24);
+        *(unsigned *)p = mm_pack_rgba8(rt.v[0], rt.v[1], rt.v[2], rt.v[3]);      // one aligned 32-bit store
         return;
     }
+    // new_template.c.in:279-293: the products are double, the conversion to a byte truncates
     if (bpp == 1 || bpp == 2)
         p[0] = (mm_clamp01(rt.v[0]) * 0.299 + mm_clamp01(rt.v[1]) * 0.587 + mm_clamp01(rt.v[2]) * 0.114) * 255.0;
     else {
@@ -690,6 +765,18 @@ MM_DEV void mm_store_pixel(const mm_args &A, int row_in_launch, int col, const m
         p[2] = mm_clamp01(rt.v[2]) * 255.0;
     }
     if (bpp == 2 || bpp == 4) p[bpp - 1] = mm_clamp01(rt.v[3]) * 255.0;
+}
+
+// a pixel whose four channels are one hot bilinear fetch, unchanged (every pure distortion ends like this)
+MM_DEV void mm_store_fetched_pixel(const mm_args &A, int row_in_launch, int col, const mm_bilinear &s) {
+    if (__builtin_expect(!A.floatmap && A.output_bpp == 4, 1)) {
+        *(unsigned *)((unsigned char *)A.out + (long)row_in_launch * A.row_stride + (long)col * 4) = mm_pack_bytes(s);
+        return;
+    }
+    const mm_f2 rg = mm_bytes_to_unit(s.rg), ba = mm_bytes_to_unit(s.ba);
+    mm_tup<4> t;
+    t.v[0] = rg.x; t.v[1] = rg.y; t.v[2] = ba.x; t.v[3] = ba.y;
+    mm_store_pixel(A, row_in_launch, col, t);
 }
 
 #endif  // MM_DEVICE_H

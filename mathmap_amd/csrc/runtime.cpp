@@ -603,7 +603,7 @@ static int upload_tables(mmhip_invocation *inv, hipStream_t s) {
 static int rows_per_item(const KernelSource &ks, int tiles_x, int num_rows) {
     // rows per work-item: enough workgroups must remain to fill 256 CUs several times over
     const long wg1 = (long)tiles_x * ((num_rows + ks.tile_h - 1) / ks.tile_h);
-    int ppt = wg1 >= 131072 ? 8 : wg1 >= 32768 ? 4 : wg1 >= 8192 ? 2 : 1;
+    int ppt = wg1 >= 262144 ? 16 : wg1 >= 131072 ? 8 : wg1 >= 32768 ? 4 : wg1 >= 8192 ? 2 : 1;
     if (const char *e = getenv("MMHIP_PPT")) ppt = std::max(1, atoi(e));
     if (ks.single_pixel) ppt = 1;
     const int u = std::max(1, ks.unroll);          // the kernel steps MM_UNROLL rows at a time
