@@ -244,6 +244,74 @@ bool loop_cse_block(FilterCode &code, Block &blk) {
 
 bool loop_carried_cse(FilterCode &code) { return loop_cse_block(code, code.body); }
 
+// ---------------------------------------------------------------------------
+// Common subexpressions
+// ---------------------------------------------------------------------------
+// `v = op(args)` where a dominating statement already computed the same pure operator on the same operand values
+// into a compvar of the same type becomes the copy `v = w` (copy propagation then removes it).  ADD and MUL match
+// with their operands in either order: the complex product the front-end emits for z * z computes a*b and b*a.
+// SSA values never change, so whatever an enclosing block has computed is still valid inside its ifs and loops.
+namespace {
+
+std::string prim_key(const Primary &p) {
+    char buf[64];
+    switch (p.kind) {
+        case Primary::Val: snprintf(buf, sizeof buf, "v%p", (const void *)p.value); break;
+        case Primary::IntConst: snprintf(buf, sizeof buf, "i%d", p.i); break;
+        case Primary::FloatConst: { unsigned u; memcpy(&u, &p.f, 4); snprintf(buf, sizeof buf, "f%08x", u); break; }
+        case Primary::ComplexConst: { unsigned u, w; memcpy(&u, &p.f, 4); memcpy(&w, &p.f2, 4); snprintf(buf, sizeof buf, "c%08x_%08x", u, w); break; }
+        case Primary::ColorConst: snprintf(buf, sizeof buf, "k%08x", p.color); break;
+        default: snprintf(buf, sizeof buf, "?"); break;
+    }
+    return buf;
+}
+
+bool cse_block(Block &blk, std::vector<std::map<std::string, Value *>> &scopes) {
+    bool changed = false;
+    scopes.emplace_back();
+    for (Stmt *s : blk) {
+        if (s->kind == Stmt::Assign && s->rhs.kind == Rhs::Op && s->rhs.op->pure && s->lhs->index >= 0) {
+            std::vector<std::string> keys;
+            bool ok = true;
+            for (const Primary &p : s->rhs.args) {
+                if (p.kind == Primary::Val && p.value->index < 0) ok = false;      // uninitialised reads: leave alone
+                keys.push_back(prim_key(p));
+            }
+            if (ok) {
+                const char *cn = s->rhs.op->cname;
+                if (keys.size() == 2 && (!strcmp(cn, "ADD") || !strcmp(cn, "MUL")) && keys[1] < keys[0]) std::swap(keys[0], keys[1]);
+                std::string key = std::string(cn) + "/" + std::to_string((int)s->lhs->var->type) + "/" + std::to_string(s->lhs->var->tuple_len);
+                for (const std::string &k : keys) key += "," + k;
+                Value *have = nullptr;
+                for (auto it = scopes.rbegin(); it != scopes.rend() && !have; ++it) {
+                    auto f = it->find(key);
+                    if (f != it->end()) have = f->second;
+                }
+                if (have) {
+                    s->rhs = Rhs::V(have);
+                    changed = true;
+                } else {
+                    scopes.back()[key] = s->lhs;
+                }
+            }
+        } else if (s->kind == Stmt::If) {
+            changed |= cse_block(s->then_, scopes);
+            changed |= cse_block(s->else_, scopes);
+        } else if (s->kind == Stmt::While) {
+            changed |= cse_block(s->body, scopes);
+        }
+    }
+    scopes.pop_back();
+    return changed;
+}
+
+}  // namespace
+
+bool common_subexpressions(FilterCode &code) {
+    std::vector<std::map<std::string, Value *>> scopes;
+    return cse_block(code.body, scopes);
+}
+
 void optimize(FilterCode &code) {
     propagate_types(code);
     for (int i = 0; i < 20; ++i) {
@@ -251,7 +319,8 @@ void optimize(FilterCode &code) {
         c |= eliminate_dead_code(code);
         if (!c) break;
     }
-    if (loop_carried_cse(code)) {
+    bool cse = !getenv("MMHIP_NO_CSE") && common_subexpressions(code);
+    if (loop_carried_cse(code) || cse) {
         propagate_types(code);
         for (int i = 0; i < 20; ++i) {
             bool c = copy_propagate(code);

@@ -8,6 +8,7 @@ namespace mm {
 bool copy_propagate(FilterCode &code);
 bool eliminate_dead_code(FilterCode &code);
 bool loop_carried_cse(FilterCode &code);
+bool common_subexpressions(FilterCode &code);
 void optimize(FilterCode &code);
 void analyze_frame_constants(FilterCode &code);
 void specialize_constants(FilterCode &code);   // specialize.cpp
