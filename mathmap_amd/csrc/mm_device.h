@@ -383,12 +383,22 @@ template <int N> MM_DEV mm_tup<N> mm_tv_set(int i, mm_tup<N> tv, float v) {
     return tv;
 }
 
+// k / 255 for an integer-valued float k in [0, 255], two channels at a time: bit-identical to
+// MM_BYTE_TO_UNIT's (float)((double)k * (1.0 / 255.0)) -- both are the correctly rounded
+// quotient (enumerated for all 256 values, tests/test_cpu_suite.py) -- by one Newton step on
+// the f32 product: q = k*r, q' = q + (k - 255 q) r with the residual exact in an fma.
+MM_DEV mm_f2 mm_bytes_to_unit(mm_f2 k) {
+    const float r = 1.0f / 255.0f;
+    const mm_f2 q = k * r;
+    const mm_f2 e = __builtin_elementwise_fma(mm_f2{-255.0f, -255.0f}, q, k);
+    return __builtin_elementwise_fma(e, mm_f2{r, r}, q);
+}
+
+// TUPLE_FROM_COLOR (opmacros.h): the four bytes of a colour as unit floats
 MM_DEV mm_tup<4> mm_tuple_from_color(color_t c) {
+    const mm_f2 rg = mm_bytes_to_unit(mm_f2{(float)RED(c), (float)GREEN(c)}), ba = mm_bytes_to_unit(mm_f2{(float)BLUE(c), (float)ALPHA(c)});
     mm_tup<4> t;
-    t.v[0] = RED_FLOAT(c);
-    t.v[1] = GREEN_FLOAT(c);
-    t.v[2] = BLUE_FLOAT(c);
-    t.v[3] = ALPHA_FLOAT(c);
+    t.v[0] = rg.x; t.v[1] = rg.y; t.v[2] = ba.x; t.v[3] = ba.y;
     return t;
 }
 
@@ -521,39 +531,6 @@ MM_DEV color_t mm_x86_byte(float v) {
     return ((v < 0.0f) ? (0u - u) : u) & 0xffu;
 }
 
-template <bool HOT>
-MM_DEV color_t mm_orig_val_intersample_pixel(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
-    x = (x + d.middle_x) * d.scale_x;
-    y = -((y - d.middle_y) * d.scale_y);
-    int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;     // == (int)floor((double)x) on x86-64
-    int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
-    float x2fact = x - x1, y2fact = y - y1;
-    // reference: 1.0 - x2fact in double, rounded to float: the double difference is exact,
-    // so this is the correctly rounded float subtraction
-    float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
-    float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
-    color_t p1, p2, p3, p4;
-    if (HOT) {
-        p1 = mm_get_pixel(A, d, x1, y1);
-        p2 = mm_get_pixel(A, d, x1, y2);
-        p3 = mm_get_pixel(A, d, x2, y1);
-        p4 = mm_get_pixel(A, d, x2, y2);
-    } else {
-        p1 = mm_get_pixel_cold(A, d, x1, y1, frame);
-        p2 = mm_get_pixel_cold(A, d, x1, y2, frame);
-        p3 = mm_get_pixel_cold(A, d, x2, y1, frame);
-        p4 = mm_get_pixel_cold(A, d, x2, y2, frame);
-    }
-    float r = RED(p1) * p1fact, g = GREEN(p1) * p1fact, b = BLUE(p1) * p1fact, a = ALPHA(p1) * p1fact;
-    r = r + RED(p2) * p2fact; g = g + GREEN(p2) * p2fact; b = b + BLUE(p2) * p2fact; a = a + ALPHA(p2) * p2fact;
-    r = r + RED(p3) * p3fact; g = g + GREEN(p3) * p3fact; b = b + BLUE(p3) * p3fact; a = a + ALPHA(p3) * p3fact;
-    r = r + RED(p4) * p4fact; g = g + GREEN(p4) * p4fact; b = b + BLUE(p4) * p4fact; a = a + ALPHA(p4) * p4fact;
-    if (x1 == (int)0x80000000 || y1 == (int)0x80000000)      // invalid coordinate: garbage sums, exact conversion
-        return MAKE_RGBA_COLOR(mm_x86_byte(rintf(r)), mm_x86_byte(rintf(g)), mm_x86_byte(rintf(b)), mm_x86_byte(rintf(a)));
-    return MAKE_RGBA_COLOR((color_t)rintf(r) & 0xff, (color_t)rintf(g) & 0xff, (color_t)rintf(b) & 0xff,
-                           (color_t)rintf(a) & 0xff);
-}
-
 MM_DEV mm_tup<4> mm_floatmap_pixel(const mm_image_desc &d, float x, float y) {
     mm_tup<4> t;
     int ix = (int)lrintf(d.ax * x + d.bx);
@@ -583,13 +560,14 @@ MM_DEV mm_image_desc mm_load_desc(const mm_args &A, mm_image img) {
     return A.images[img.idx];
 }
 
+MM_DEV mm_tup<4> mm_intersample_tuple_cold(const mm_args &A, const mm_image_desc &d, float x, float y, int frame);
 // opmacros.h:199-216 (closure images are applied at compile time and never reach here)
 MM_DEV mm_tup<4> mm_orig_val_d(const mm_args &A, float x, float y, mm_image img, float f, const mm_image_desc &d) {
     if (img.resized) { x *= img.xf; y *= img.yf; }
     if (img.idx < 0) { mm_tup<4> t; t.v[0] = t.v[1] = t.v[2] = t.v[3] = 1.0f; return t; }
     if (d.kind == MM_IMG_FLOATMAP) return mm_floatmap_pixel(d, x, y);
 #if MM_INTERSAMPLE
-    return mm_tuple_from_color(mm_orig_val_intersample_pixel<false>(A, d, x, y, mm_f2i(f)));
+    return mm_intersample_tuple_cold(A, d, x, y, mm_f2i(f));
 #else
     return mm_tuple_from_color(mm_orig_val_pixel<false>(A, d, x, y, mm_f2i(f)));
 #endif
@@ -599,16 +577,6 @@ MM_DEV mm_tup<4> mm_orig_val_d(const mm_args &A, float x, float y, mm_image img,
 // of consecutive unrolled pixels can overlap.  x * 1.0f is x, so the resize factors are
 // applied by multiplication with a selected factor instead of under `if (img.resized)`.
 
-// k / 255 for an integer-valued float k in [0, 255], two channels at a time: bit-identical to
-// MM_BYTE_TO_UNIT's (float)((double)k * (1.0 / 255.0)) -- both are the correctly rounded
-// quotient (enumerated for all 256 values, tests/test_cpu_suite.py) -- by one Newton step on
-// the f32 product: q = k*r, q' = q + (k - 255 q) r with the residual exact in an fma.
-MM_DEV mm_f2 mm_bytes_to_unit(mm_f2 k) {
-    const float r = 1.0f / 255.0f;
-    const mm_f2 q = k * r;
-    const mm_f2 e = __builtin_elementwise_fma(mm_f2{-255.0f, -255.0f}, q, k);
-    return __builtin_elementwise_fma(e, mm_f2{r, r}, q);
-}
 
 // get_orig_val_intersample_pixel + TUPLE_FROM_COLOR for a hot image, fused: same operations
 // in the same order per channel (builtins.c:202-250), two channels per packed instruction;
@@ -617,6 +585,38 @@ MM_DEV mm_f2 mm_bytes_to_unit(mm_f2 k) {
 // `bad` is raised for a coordinate that is NaN / infinite / beyond +-2^31 pixels: the caller then
 // discards this result and re-evaluates the pixel through the generic path (mm_x86_byte above).
 struct mm_bilinear { mm_f2 rg, ba; };      // the four rounded channel sums: integer-valued floats in [0, 255]
+
+// All four taps of every lane inside the image -- the case of nearly every wave: no clamping, no edge colours, and
+// the taps are two 8-byte loads (x1 and x1 + 1 are neighbours in a row; global loads only need dword alignment)
+// whose addresses cost three instructions.  Wave-uniform.  (One ballot per comparison: each is the v_cmp's lane
+// mask itself, the OR is scalar.  An INT_MIN coordinate counts as outside.)
+MM_DEV bool mm_taps_all_inside(const mm_image_desc &d, int x1, int y1) {
+    return (__builtin_amdgcn_ballot_w64((unsigned)x1 >= (unsigned)(d.w - 1)) |
+            __builtin_amdgcn_ballot_w64((unsigned)y1 >= (unsigned)(d.h - 1))) == 0;
+}
+MM_DEV void mm_load_taps_inside(const mm_image_desc &d, int x1, int y1, color_t &p1, color_t &p2, color_t &p3, color_t &p4) {
+    typedef unsigned mm_u2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) mm_u2 *mm_gpix2;
+    const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)d.data;
+    const unsigned boff = (__umul24((unsigned)y1, (unsigned)d.w) + (unsigned)x1) << 2;
+    const mm_u2 top = *(mm_gpix2)(base + boff), bot = *(mm_gpix2)(base + (boff + ((unsigned)d.w << 2)));
+    p1 = top.x; p3 = top.y; p2 = bot.x; p4 = bot.y;
+}
+// get_orig_val_intersample_pixel's weighted sums (builtins.c:228-247), same operations in the same order per
+// channel, two channels per packed instruction
+MM_DEV void mm_bilinear_sums(color_t p1, color_t p2, color_t p3, color_t p4, float x2fact, float y2fact, mm_f2 &rg, mm_f2 &ba) {
+    // reference: 1.0 - x2fact in double, rounded to float: the double difference is exact, so this is the
+    // correctly rounded float subtraction
+    const float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
+    const float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
+    rg = mm_f2{(float)RED(p1), (float)GREEN(p1)} * p1fact; ba = mm_f2{(float)BLUE(p1), (float)ALPHA(p1)} * p1fact;
+    rg = rg + mm_f2{(float)RED(p2), (float)GREEN(p2)} * p2fact;
+    ba = ba + mm_f2{(float)BLUE(p2), (float)ALPHA(p2)} * p2fact;
+    rg = rg + mm_f2{(float)RED(p3), (float)GREEN(p3)} * p3fact;
+    ba = ba + mm_f2{(float)BLUE(p3), (float)ALPHA(p3)} * p3fact;
+    rg = rg + mm_f2{(float)RED(p4), (float)GREEN(p4)} * p4fact;
+    ba = ba + mm_f2{(float)BLUE(p4), (float)ALPHA(p4)} * p4fact;
+}
 
 MM_DEV mm_bilinear mm_intersample_sums_hot(const mm_args &A, const mm_image_desc &d, float x, float y, bool &bad) {
     x = (x + d.middle_x) * d.scale_x;
@@ -631,38 +631,45 @@ MM_DEV mm_bilinear mm_intersample_sums_hot(const mm_args &A, const mm_image_desc
     y = ok_y ? y : 0.0f;
     const int x1 = (int)floorf(x), x2 = x1 + 1;
     const int y1 = (int)floorf(y), y2 = y1 + 1;
-    const float x2fact = x - x1, y2fact = y - y1;
-    const float x1fact = 1.0f - x2fact, y1fact = 1.0f - y2fact;
-    const float p1fact = x1fact * y1fact, p2fact = x1fact * y2fact, p3fact = x2fact * y1fact, p4fact = x2fact * y2fact;
     color_t p1, p2, p3, p4;
-    // All four taps of every lane inside the image -- the case of nearly every wave: no clamping, no edge
-    // colours, and the taps are two 8-byte loads (x1, x2 are neighbours in a row; global loads only need dword
-    // alignment) whose addresses cost three instructions.  The branch is wave-uniform.
-    // (one ballot per comparison: each is the v_cmp's lane mask itself, the OR is scalar)
-    const bool all_inside = (__builtin_amdgcn_ballot_w64((unsigned)x1 >= (unsigned)(d.w - 1)) |
-                             __builtin_amdgcn_ballot_w64((unsigned)y1 >= (unsigned)(d.h - 1))) == 0;
-    if (__builtin_expect(all_inside, 1)) {
-        typedef unsigned mm_u2 __attribute__((ext_vector_type(2)));
-        typedef const __attribute__((address_space(1))) mm_u2 *mm_gpix2;
-        const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)d.data;
-        const unsigned boff = (__umul24((unsigned)y1, (unsigned)d.w) + (unsigned)x1) << 2;
-        const mm_u2 top = *(mm_gpix2)(base + boff), bot = *(mm_gpix2)(base + (boff + ((unsigned)d.w << 2)));
-        p1 = top.x; p3 = top.y; p2 = bot.x; p4 = bot.y;
-    } else {
+    if (__builtin_expect(mm_taps_all_inside(d, x1, y1), 1)) mm_load_taps_inside(d, x1, y1, p1, p2, p3, p4);
+    else {
         p1 = mm_get_pixel(A, d, x1, y1); p2 = mm_get_pixel(A, d, x1, y2);
         p3 = mm_get_pixel(A, d, x2, y1); p4 = mm_get_pixel(A, d, x2, y2);
     }
-    mm_f2 rg = mm_f2{(float)RED(p1), (float)GREEN(p1)} * p1fact, ba = mm_f2{(float)BLUE(p1), (float)ALPHA(p1)} * p1fact;
-    rg = rg + mm_f2{(float)RED(p2), (float)GREEN(p2)} * p2fact;
-    ba = ba + mm_f2{(float)BLUE(p2), (float)ALPHA(p2)} * p2fact;
-    rg = rg + mm_f2{(float)RED(p3), (float)GREEN(p3)} * p3fact;
-    ba = ba + mm_f2{(float)BLUE(p3), (float)ALPHA(p3)} * p3fact;
-    rg = rg + mm_f2{(float)RED(p4), (float)GREEN(p4)} * p4fact;
-    ba = ba + mm_f2{(float)BLUE(p4), (float)ALPHA(p4)} * p4fact;
+    mm_f2 rg, ba;
+    mm_bilinear_sums(p1, p2, p3, p4, x - x1, y - y1, rg, ba);
     mm_bilinear r;      // rintf of a sum in [0, 255.001) is a byte: (color_t)rintf(v) & 0xff changes nothing
     r.rg = mm_f2{rintf(rg.x), rintf(rg.y)};
     r.ba = mm_f2{rintf(ba.x), rintf(ba.y)};
     return r;
+}
+
+// The general fetch (any image kind, any frame number; what large filter bodies use throughout): the reference's
+// order of tests per tap, each an early exit -- a wave whose lanes all sample outside the image, like most of
+// Droste's outer levels, issues no load at all.
+MM_DEV mm_tup<4> mm_intersample_tuple_cold(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
+    x = (x + d.middle_x) * d.scale_x;
+    y = -((y - d.middle_y) * d.scale_y);
+    const int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;     // == (int)floor((double)x) on x86-64
+    const int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
+    color_t p1, p2, p3, p4;
+    // (the two-load form of the hot fetch was tried here as well, for waves whose taps are all inside a bound
+    // drawable: Droste 8192^2 went from 1.83 to 2.05 ms with it)
+    p1 = mm_get_pixel_cold(A, d, x1, y1, frame); p2 = mm_get_pixel_cold(A, d, x1, y2, frame);
+    p3 = mm_get_pixel_cold(A, d, x2, y1, frame); p4 = mm_get_pixel_cold(A, d, x2, y2, frame);
+    mm_f2 rg, ba;
+    mm_bilinear_sums(p1, p2, p3, p4, x - x1, y - y1, rg, ba);
+    rg = mm_f2{rintf(rg.x), rintf(rg.y)};
+    ba = mm_f2{rintf(ba.x), rintf(ba.y)};
+    if (x1 == (int)0x80000000 || y1 == (int)0x80000000)      // invalid coordinate: garbage sums, exact conversion
+        return mm_tuple_from_color(MAKE_RGBA_COLOR(mm_x86_byte(rg.x), mm_x86_byte(rg.y), mm_x86_byte(ba.x), mm_x86_byte(ba.y)));
+    // a valid coordinate has weights in [0, 1]: the sums are in [0, 255.001) and (color_t)rintf(v) & 0xff is rintf(v)
+    rg = mm_bytes_to_unit(rg);
+    ba = mm_bytes_to_unit(ba);
+    mm_tup<4> t;
+    t.v[0] = rg.x; t.v[1] = rg.y; t.v[2] = ba.x; t.v[3] = ba.y;
+    return t;
 }
 
 MM_DEV mm_tup<4> mm_intersample_tuple_hot(const mm_args &A, const mm_image_desc &d, float x, float y, bool &bad) {
