@@ -863,6 +863,45 @@ def test_recursive_filter_calls_filter_functions_on_the_gpu():
     assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[1], outs[2])
 
 
+PACK_RAMP = """
+filter ramp (float spread: 0-1 (0.00001))
+  kk = floor((x + 1) * 128.5);
+  off = y * spread;
+  c = (kk + off) / 255;
+  rgba:[c, 1 - c, c * c, (kk - 3 + off * 7) / 249]
+end
+"""
+
+
+def test_rgba8_pack_and_fetched_pixel_store_on_values_around_every_byte_boundary():
+    """The pack without f64 (one round-toward-zero fma per channel, mm_pack_rgba8) against the template's
+    (unsigned char)(c * 255.0), which the oracle executes: channel values within a few ulps of every k / 255, on
+    both sides, and values outside [0, 1] and NaN-free extremes.  Then the store of an unchanged bilinear fetch
+    (mm_store_fetched_pixel: the fetch's rounded byte sums, no division / product) for all 256 byte values in
+    every channel, at fractional offsets."""
+    w, h = 1024, 512
+    for spread in (1e-5, 3e-7, 0.4):
+        flt, got = hip_render(PACK_RAMP, w, h, {"spread": spread})
+        want = cpu_render(flt, w, h, {"spread": spread})
+        assert np.array_equal(got, want), (spread, stats(got, want))
+        assert len(np.unique(got[..., 0])) >= 250
+    # every byte value in every channel, sampled between texel centres
+    img = np.zeros((64, 256, 4), np.uint8)
+    v = np.arange(256, dtype=np.uint8)[None, :]
+    img[..., 0] = v; img[..., 1] = 255 - v; img[..., 2] = (v.astype(int) * 7 % 256).astype(np.uint8); img[..., 3] = (v[:, ::-1] // 2 + 64)
+    img[1::2] = img[1::2, ::-1]
+    src = "filter shift (image in, float dx: -1-1 (0.001), float dy: -1-1 (0.002))\n  in(xy + xy:[dx, dy])\nend\n"
+    for dx, dy in ((0.0, 0.0), (0.0013, 0.0021), (-0.004, 0.0097), (0.3, -0.2)):
+        flt = mm.Filter(src)
+        assert "mm_store_fetched_pixel(A, rl_raw" in flt.kernel_source
+        inv = flt.invoke(256, 64)
+        inv.set_image("in", img)
+        inv.set("dx", dx); inv.set("dy", dy)
+        got = inv.render()
+        want = CpuFilter(flt.ir_json_raw).render(256, 64, uservals={"dx": dx, "dy": dy}, images={"in": img})
+        assert np.array_equal(got, want), ((dx, dy), stats(got, want))
+
+
 def test_data_dependent_recursion_on_the_gpu():
     """The recursion depth differs per pixel (it follows the image content and the position), which no
     lowering-time unrolling could serve; mutual recursion between two filters; RAND inside the callee keeps the
