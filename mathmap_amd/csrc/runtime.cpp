@@ -220,10 +220,26 @@ static int jit_source(const KernelSource &ks, std::vector<char> &code_object) {
     }
     std::string path = cache_dir() + "/" + ks.key + "_o2" + extra_key + ".hsaco";   // _o2: option-set version
     std::ifstream in(path, std::ios::binary);
-    if (in && !getenv("MMHIP_NO_CACHE")) code_object.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+    const char *ov = getenv("MMHIP_SOURCE_OVERRIDE");
+    const bool may_override = ov && !strncmp(ov, ks.key.c_str(), ks.key.size()) && ov[ks.key.size()] == ':';
+    if (in && !getenv("MMHIP_NO_CACHE") && !may_override) code_object.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
     if (!code_object.empty()) return 0;
+    // kernel experiments: MMHIP_SOURCE_OVERRIDE=<key>:<file> compiles the file's text in place of the generated kernel
+    // with that key (hand-edited variants of one kernel under the unchanged launch code; never cached)
+    std::string source = ks.source;
+    bool overridden = false;
+    if (const char *e = getenv("MMHIP_SOURCE_OVERRIDE")) {
+        const std::string spec = e;
+        const size_t c = spec.find(':');
+        if (c != std::string::npos && spec.substr(0, c) == ks.key) {
+            std::ifstream f(spec.substr(c + 1));
+            if (!f) return fail("MMHIP_SOURCE_OVERRIDE: cannot read " + spec.substr(c + 1));
+            source.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            overridden = true;
+        }
+    }
     hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, ks.source.c_str(), "mathmap_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    if (hiprtcCreateProgram(&prog, source.c_str(), "mathmap_filter.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail("hiprtcCreateProgram failed");
     // -fno-slp-vectorize: the SLP vectoriser packs scalar f32 chains into v_pk_* at the price of
     // register shuffles (Mandelbrot's loop: 11 VALU with it, 10 without; measured +9 %); the
@@ -244,6 +260,7 @@ static int jit_source(const KernelSource &ks, std::vector<char> &code_object) {
     code_object.resize(n);
     hiprtcGetCode(prog, code_object.data());
     hiprtcDestroyProgram(&prog);
+    if (overridden) return 0;
     std::string tmp = path + ".tmp" + std::to_string((int)getpid());
     std::ofstream o(tmp, std::ios::binary);
     if (o) {
