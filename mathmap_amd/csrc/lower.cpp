@@ -460,7 +460,10 @@ void Lowerer::native_image_argument(CompVar *image, bool stripped) {
     for (int i = 0; i < 4; ++i) {
         target_result_[i] = res[i]->current;
         const Stmt *d = target_result_[i] ? target_result_[i]->def : nullptr;
-        if (d && d->parent) throw CompileError("a filter closure passed to a native filter inside a conditional is not supported");
+        // the value has to exist at the top level of the body: a top-level statement, or an exit / entry phi of a
+        // top-level `if' / `while' (a phi's parent is the construct it belongs to)
+        const Stmt *scope = d ? (d->kind == Stmt::Phi && d->parent ? d->parent->parent : d->parent) : nullptr;
+        if (scope) throw CompileError("a filter closure passed to a native filter inside a conditional is not supported");
     }
     target_done_ = true;
 }

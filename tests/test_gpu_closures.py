@@ -74,6 +74,29 @@ def test_native_filter_on_closure_image(name, src, tol):
     assert np.array_equal(full, banded)
 
 
+def test_native_filter_on_a_recursive_closure():
+    """The closure handed to the blur is a recursive filter whose body ends in an `if` (its result values are exit
+    phis of a top-level construct) and calls itself at run time: the closure's render kernel calls the main code's
+    filter functions (generate_hip(..., functions_of)).  Generic kernel = oracle = kernel with the depth baked in."""
+    w, h = 160, 96
+    img = W.synthetic_image(w, h, seed=3)
+    src = W.RECURSIVE + """
+filter blurred_tree (image in, int depth: 1-16 (3), float dev: 0-1 (0.02))
+  b = gaussian_blur(tree(in, depth, 0.7), dev, dev);
+  b(xy)
+end
+"""
+    flt, inv = make_invocation(src, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for depth in (1, 3, 6):
+        inv.set("depth", depth)
+        got = inv.render(t=0.25)
+        want = cf.render(w, h, uservals={"depth": depth}, images={"in": img}, t=0.25)
+        assert np.array_equal(got, want), (depth, stats(got, want))
+        sp, si = make_invocation(src, w, h, {"depth": depth}, {"in": img}, specialize=True)
+        assert np.array_equal(si.render(t=0.25), got), depth
+
+
 def test_convolve_on_closure_image():
     w, h = 96, 64
     img = W.synthetic_image(w, h, seed=3)
