@@ -16,9 +16,10 @@
 //       pair mode    : loop shape for small arithmetic-only bodies -- two vertically adjacent pixels as
 //                      pairs of values in lockstep (two interleaved instruction streams), see pair_stmts
 //
-// Environment hooks for experiments (never needed for correct operation): MMHIP_UNROLL,
-// MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU here; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE,
-// MMHIP_CACHE_DIR in runtime.cpp.
+// Environment hooks for experiments (never needed for correct operation): MMHIP_UNROLL, MMHIP_TILE_W,
+// MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU, MMHIP_NO_FETCHED_RESULT, MMHIP_NO_SAME_TAPS,
+// MMHIP_MAX_CALL_DEPTH here; MMHIP_NO_CSE in passes.cpp; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE, MMHIP_CACHE_DIR,
+// MMHIP_SOURCE_OVERRIDE in runtime.cpp.
 //
 // Statement printing follows the reference's backends/cc.c:192-397 (one C variable
 // per SSA value, phi copies at the end of branches / loop bodies), so the arithmetic
@@ -1055,6 +1056,7 @@ struct Generator {
         if (tw != 8 && tw != 16 && tw != 32 && tw != 64 && tw != 128 && tw != 256) tw = auto_tile_w();
         ks.tile_w = tw;
         ks.tile_h = 256 / tw;
+        if (getenv("MMHIP_NO_SAME_TAPS")) out << "#define MM_NO_SAME_TAPS 1\n";      // A/B switch
         out << "#define MM_INTERSAMPLE " << opt.intersample << "\n";
         out << "#define MM_SUPERSAMPLING " << opt.supersampling << "\n";
         out << "#define MM_EDGE_X " << opt.edge_x << "\n#define MM_EDGE_Y " << opt.edge_y << "\n";

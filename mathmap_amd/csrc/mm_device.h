@@ -659,11 +659,18 @@ MM_DEV mm_tup<4> mm_intersample_tuple_cold(const mm_args &A, const mm_image_desc
     // region that waves without a tap to load skip (1.87 ms).
     p1 = mm_get_pixel_cold(A, d, x1, y1, frame); p2 = mm_get_pixel_cold(A, d, x1, y2, frame);
     p3 = mm_get_pixel_cold(A, d, x2, y1, frame); p4 = mm_get_pixel_cold(A, d, x2, y2, frame);
+    const bool wild = x1 == (int)0x80000000 || y1 == (int)0x80000000;
+#ifndef MM_NO_SAME_TAPS
+    // Four equal taps -- every lane of a wave sampling outside the image (Droste's outer levels) gets four times
+    // the edge colour -- need no interpolation: the weights are in [0, 1] and sum to 1 within 2^-22, so each
+    // channel's sum is within 255 * 2^-21 of the common byte and rintf returns that byte.  Wave-uniform test.
+    if (__builtin_amdgcn_ballot_w64(wild || p1 != p2 || p1 != p3 || p1 != p4) == 0) return mm_tuple_from_color(p1);
+#endif
     mm_f2 rg, ba;
     mm_bilinear_sums(p1, p2, p3, p4, x - x1, y - y1, rg, ba);
     rg = mm_f2{rintf(rg.x), rintf(rg.y)};
     ba = mm_f2{rintf(ba.x), rintf(ba.y)};
-    if (x1 == (int)0x80000000 || y1 == (int)0x80000000)      // invalid coordinate: garbage sums, exact conversion
+    if (wild)      // invalid coordinate: garbage sums, exact conversion
         return mm_tuple_from_color(MAKE_RGBA_COLOR(mm_x86_byte(rg.x), mm_x86_byte(rg.y), mm_x86_byte(ba.x), mm_x86_byte(ba.y)));
     // a valid coordinate has weights in [0, 1]: the sums are in [0, 255.001) and (color_t)rintf(v) & 0xff is rintf(v)
     rg = mm_bytes_to_unit(rg);
