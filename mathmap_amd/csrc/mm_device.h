@@ -653,13 +653,25 @@ MM_DEV mm_tup<4> mm_intersample_tuple_cold(const mm_args &A, const mm_image_desc
     y = -((y - d.middle_y) * d.scale_y);
     const int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;     // == (int)floor((double)x) on x86-64
     const int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
+    const bool wild = x1 == (int)0x80000000 || y1 == (int)0x80000000;
+#if MM_EDGE_X == 0 && MM_EDGE_Y == 0 && !defined(MM_NO_OUTSIDE_SHORTCUT)
+    // Every lane of the wave entirely outside a bound image (most fetches of Droste's level loop): get_pixel answers
+    // x outside -> edge colour x, else y outside -> edge colour y, so a lane whose two columns are both outside has
+    // four taps of edge colour x, one whose columns are both inside and whose rows are both outside four of edge
+    // colour y -- and four equal taps are that colour (below).  Known from x1, y1 alone: no taps at all.
+    if (d.kind != MM_IMG_NULL) {
+        const bool x_out = (unsigned)x1 + 1u > (unsigned)d.w, x_in = (unsigned)x1 < (unsigned)(d.w - 1);
+        const bool y_out = (unsigned)y1 + 1u > (unsigned)d.h;
+        if (__builtin_amdgcn_ballot_w64(wild || !(x_out || (x_in && y_out))) == 0)
+            return mm_tuple_from_color(x_out ? A.edge_color_x : A.edge_color_y);
+    }
+#endif
     color_t p1, p2, p3, p4;
     // Two alternatives were measured on Droste 8192^2 (1.79 ms as it is): the two-load form of the hot fetch for waves
     // whose taps are all inside a bound drawable (2.05 ms), and branch-free taps with clamped addresses inside one
     // region that waves without a tap to load skip (1.87 ms).
     p1 = mm_get_pixel_cold(A, d, x1, y1, frame); p2 = mm_get_pixel_cold(A, d, x1, y2, frame);
     p3 = mm_get_pixel_cold(A, d, x2, y1, frame); p4 = mm_get_pixel_cold(A, d, x2, y2, frame);
-    const bool wild = x1 == (int)0x80000000 || y1 == (int)0x80000000;
 #ifndef MM_NO_SAME_TAPS
     // Four equal taps -- every lane of a wave sampling outside the image (Droste's outer levels) gets four times
     // the edge colour -- need no interpolation: the weights are in [0, 1] and sum to 1 within 2^-22, so each
