@@ -244,8 +244,10 @@ def host_delivered_rate(torch, wl, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: two passes over the 120-frame animation after 24 untimed frames -- 20 frames of Mandelbrot are 7 ms of
+    # GPU work, over before the clocks have settled (measured: 0.326 ms per frame with --steps 20, 0.304 with 120)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--workload", default="mandelbrot", choices=sorted(ALGO_BYTES_PER_PIXEL))
     ap.add_argument("--size", type=int, default=0, help="frame edge in pixels (default 8192; 16384 for gauss)")
     ap.add_argument("--tile-w", type=int, default=0)

@@ -15,8 +15,8 @@ for w in $WL; do
     droste_nt) ARGS="--workload droste -D NoTransparency=1" ;;
     *) ARGS="--workload $w" ;;
   esac
-  STEPS=10; PSTEPS=4
-  if [ $w = gauss ]; then STEPS=5; PSTEPS=2; fi
+  STEPS=120; PSTEPS=4
+  if [ $w = gauss ]; then STEPS=30; PSTEPS=2; fi
   python3 bench.py $ARGS --no-extras --steps $STEPS > $O/bench_$w.log 2>&1
   rm -rf $O/stats_$w $O/pmc_fetch_$w $O/pmc_write_$w $O/pmc_sq_$w
   rocprofv3 --kernel-trace --stats -d $O/stats_$w -o st --output-format csv -- python3 bench.py $ARGS --no-extras --steps $STEPS > $O/stats_$w.log 2>&1
