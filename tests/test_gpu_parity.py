@@ -900,6 +900,14 @@ def test_rgba8_pack_and_fetched_pixel_store_on_values_around_every_byte_boundary
         got = inv.render()
         want = CpuFilter(flt.ir_json_raw).render(256, 64, uservals={"dx": dx, "dy": dy}, images={"in": img})
         assert np.array_equal(got, want), ((dx, dy), stats(got, want))
+        # the same kernel asked for a float map (and for RGB): the fetched sums go through k / 255 after all
+        from tests.gpu_util import render_device
+        gf = render_device(inv, 256, 64, floatmap=True)
+        wf = CpuFilter(flt.ir_json_raw).render(256, 64, uservals={"dx": dx, "dy": dy}, images={"in": img}, floatmap=True)
+        assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32)), (dx, dy)
+        g3 = render_device(inv, 256, 64, bpp=3)
+        w3 = CpuFilter(flt.ir_json_raw).render(256, 64, uservals={"dx": dx, "dy": dy}, images={"in": img}, bpp=3)
+        assert np.array_equal(g3, w3), (dx, dy)
 
 
 def test_data_dependent_recursion_on_the_gpu():
