@@ -1315,7 +1315,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                 << "(const mm_args &A, const mm_uvarg *UV, float x, float y, float t, int col, int rl, unsigned &mm_rand_ctr) {\n"
                    "  mm_tup<4> rt;\n  rt.v[0] = rt.v[1] = rt.v[2] = rt.v[3] = 0.0f;\n"
                    "  if constexpr (MM_D >= MM_MAX_CALL_DEPTH) { return rt; } else {\n"
-                   "  const float R = A.R; const int frame = A.frame;\n"
+                   "  const float R = A.R; const int frame = 0;      // new_template.c.in:379: filter_$name has `int frame = 0`\n"
                    "  const int __canvasPixelW = A.img_width, __canvasPixelH = A.img_height;\n"
                    "  const int __renderPixelW = A.render_width, __renderPixelH = A.render_height;\n"
                    "  (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;\n";

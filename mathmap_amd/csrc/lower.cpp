@@ -609,6 +609,10 @@ void Lowerer::gen(AstNode *n, CompVar **dest, bool alloced) {
             break;
         case AstNode::Internal: {
             if (!alloced) dest[0] = g_.temp();
+            if (in_target_body_ && n->name == "frame") {      // calc_lines_$name of a closure image runs on a frame made by
+                g_.assign(dest[0], Rhs::I(0));                // invocation_new_frame(invocation, image, 0, 0.0): frame = 0
+                break;
+            }
             auto it = env_->internals.find(n->name);
             if (it != env_->internals.end()) g_.assign(dest[0], Rhs::V(it->second));
             else g_.assign(dest[0], Rhs::Int(n->name));

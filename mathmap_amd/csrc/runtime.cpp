@@ -653,9 +653,9 @@ static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const
         HIP_TRY(hipMemset(st.d_xy, 0, xy_bytes));
         st.xy_cap = xy_bytes;
     }
+    // (t and frame stay the frame's own: the closure's *arguments* are values of the main filter's code at the current
+    // time; the closure's body is lowered with t = 0.0 and frame = 0 as literals, lower.cpp native_image_argument)
     HArgs a = main_args;
-    a.t = 0.0f;
-    a.frame = 0;
     a.region_x = a.region_y = 0;
     a.region_width = w;
     a.region_height = h;

@@ -406,6 +406,18 @@ filter echoes (image in, int n: 0-64 (6))
 end
 """
 
+# a closure image for a native filter whose argument depends on t, and whose body reads t and frame
+CLOSURE_TIMED_ARG = """
+filter inner2 (image in, float k: 0-2 (1.0))
+  in(xy * k) * 0.8 + rgba:[t * 0.5, frame * 0.01, 0.1, 0]
+end
+
+filter outer (image in, float s: 0-1 (0.03), float k: 0-2 (0.5))
+  b = gaussian_blur(inner2(in, k * (1 + t)), s, s);
+  b(xy)
+end
+"""
+
 # curve and gradient user values (the shape of examples/Colors/Colorify.mm)
 CURVE_GRADIENT = """
 filter cg (image in, curve tone, gradient colors)

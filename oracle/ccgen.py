@@ -290,7 +290,7 @@ class Gen:
             out.append(sig % k + " {")
             out.append("  mmo_tup4 rt = {{0, 0, 0, 0}};")
             out.append("  if (mm_depth >= MM_MAX_CALL_DEPTH) return rt;")
-            out.append("  const float R = A->R; const int frame = A->frame;")
+            out.append("  const float R = A->R; const int frame = 0;      /* new_template.c.in:379 */")
             out.append("  const int __canvasPixelW = A->img_width, __canvasPixelH = A->img_height;")
             out.append("  const int __renderPixelW = A->render_width, __renderPixelH = A->render_height;")
             out.append("  (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;")
@@ -586,10 +586,11 @@ class CpuFilter:
             descs.append(d)
         closure_base = -1
         if self.subs:
-            # builtins.c:273-298: frame 0, t = 0.0, the whole frame, sampling offsets 0, float map output
+            # builtins.c:273-298: the whole frame, sampling offsets 0, float map output; the closure's body has t = 0.0 and
+            # frame = 0 as literals (the frame render_image makes), its arguments are the main code's values at this t
             closure_base = len(descs)
             for sub in self.subs:
-                m = sub.render(a_img_w, a_img_h, uservals=uservals, images=images, t=0.0, frame=0, intersample=intersample,
+                m = sub.render(a_img_w, a_img_h, uservals=uservals, images=images, t=t, frame=frame, intersample=intersample,
                                floatmap=True, edge=edge, edge_colors=edge_colors, supersampling=supersampling,
                                render_size=render_size)
                 keep.append(m)

@@ -208,6 +208,18 @@ def test_userval_specialisation_preserves_results_on_cpu(name, uv):
     assert np.array_equal(a, b), np.abs(a.astype(int) - b.astype(int)).max()
 
 
+def test_closure_render_takes_arguments_at_the_current_time_and_runs_its_body_at_t_zero():
+    """render_image's closure branch (builtins.c:273-298) on the oracle: the closure's calc_lines runs on a frame with
+    t = 0.0 and frame = 0, its arguments are what the main filter's code computed at the current t."""
+    TIMED_ARG = W.CLOSURE_TIMED_ARG
+    img = W.synthetic_image(96, 64, seed=3)
+    a = CpuFilter(mm.Filter(TIMED_ARG).ir_json_raw).render(96, 64, images={"in": img}, t=0.5, frame=7)
+    fb = mm.Filter(TIMED_ARG.replace("k * (1 + t)", "k"))
+    for t, frame in ((0.0, 0), (0.9, 3)):
+        b = CpuFilter(fb.ir_json_raw).render(96, 64, uservals={"k": 0.75}, images={"in": img}, t=t, frame=frame)
+        assert np.array_equal(a, b), (t, frame)
+
+
 def test_recursive_filter_calls_at_run_time_and_unrolls_with_literals():
     """A recursive application is a run-time call of filter_$name (compiler.c:2165-2222 RHS_FILTER,
     backends/cc.c:221-235): the IR carries the callee's body under "functions" and one generic kernel serves

@@ -1,6 +1,7 @@
 """Native filters and render() applied to closure images -- render_image's closure branch
 (builtins/builtins.c:267-302): the closure's own calc_lines is launched over the whole frame with
-floatmap = 1 at frame 0, t = 0.0, and the native filter works on that float map.  HIP (through the
+floatmap = 1 at frame 0, t = 0.0 (its arguments being values of the main code at the current time), and the native
+filter works on that float map.  HIP (through the
 C ABI) against the oracle, which runs the closure's code as a filter of its own."""
 import numpy as np
 import pytest
@@ -72,6 +73,26 @@ def test_native_filter_on_closure_image(name, src, tol):
     full = inv.render(t=0.3)
     banded = render_device(inv, w, h, rows=[(0, 50), (50, 51), (51, h)], t=0.3)
     assert np.array_equal(full, banded)
+
+
+TIMED_ARG = W.CLOSURE_TIMED_ARG
+
+
+def test_closure_arguments_are_values_of_the_current_frame_and_its_body_runs_at_t_zero():
+    """render_image runs the closure's own calc_lines on a frame with t = 0.0 and frame number 0
+    (invocation_new_frame(invocation, image, 0, 0.0), builtins.c:291), but the closure's arguments were evaluated by
+    the main filter's code at the current time (backends/cc.c:158-188).  So k * (1 + t) at t = 0.5, k = 0.5 must give
+    what the constant 0.75 gives at any t and frame -- and HIP = oracle."""
+    w, h = 160, 96
+    img = W.synthetic_image(w, h, seed=3)
+    flt, inv = make_invocation(TIMED_ARG, w, h, {}, {"in": img})
+    got = inv.render(t=0.5, frame=7)
+    want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, t=0.5, frame=7)
+    assert np.array_equal(got, want), stats(got, want)
+    const = TIMED_ARG.replace("k * (1 + t)", "k")
+    f2, i2 = make_invocation(const, w, h, {"k": 0.75}, {"in": img})
+    assert np.array_equal(i2.render(t=0.0, frame=0), got)
+    assert np.array_equal(i2.render(t=0.9, frame=3), got)
 
 
 def test_native_filter_on_a_recursive_closure():
