@@ -20,6 +20,7 @@
 #include <mutex>
 
 #include "../../include/mathmap_hip_backend.h"
+#include "gen.h"
 #include "passes.h"
 #include "runtime_internal.h"
 
@@ -295,6 +296,32 @@ struct Importer {
     }
 };
 
+// Closure images that reach a native filter's image argument or render(): render_image's closure branch
+// (builtins.c:267-302).  Numbered in statement order; `out` gets each closure's defining statement and the chain of
+// resize wrappers between it and its first use.
+void number_native_closures(Block &b, std::vector<std::pair<Stmt *, ImageChain>> &out) {
+    for (Stmt *s : b) {
+        if (s->kind == Stmt::Assign) {
+            const Rhs &r = s->rhs;
+            const bool native = (r.kind == Rhs::Closure && r.filter->kind == Filter::Native) ||
+                                (r.kind == Rhs::Op && !strcmp(r.op->cname, "RENDER"));
+            if (!native) continue;
+            for (const Primary &p : r.args) {
+                if (p.kind != Primary::Val || p.value->var->type != Ty::Image) continue;
+                ImageChain ch = resolve_image_chain(p.value);
+                if (ch.base != ImageChain::MathMapClosure || ch.closure_def->closure_id >= 0) continue;
+                ch.closure_def->closure_id = (int)out.size();
+                out.push_back({ch.closure_def, ch});
+            }
+        } else if (s->kind == Stmt::If) {
+            number_native_closures(s->then_, out);
+            number_native_closures(s->else_, out);
+        } else if (s->kind == Stmt::While) {
+            number_native_closures(s->body, out);
+        }
+    }
+}
+
 int option_key(const KernelOptions &k) {
     return (k.intersample & 1) | ((k.supersampling & 1) << 1) | ((k.edge_x & 3) << 2) | ((k.edge_y & 3) << 4);
 }
@@ -511,6 +538,47 @@ mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_i
             imp.block(main_code->first_stmt, f->code->body, nullptr);
             imp.find_result();
             propagate_types(*f->code);      // the types are the reference's; this fills in the tuple / tree-vector lengths
+            // The render code of every closure image a native filter (or render()) is given: the main code once more
+            // -- it computes the closure's arguments, at the frame's own time -- followed by a call of the closure's
+            // filter function at the pixel's raw coordinates with t = 0.0 (the function's own `frame' is 0), its value
+            // as the result.  What the call does not need is dead code for the ordinary passes.  (The standalone
+            // tier inlines the closure's body instead, lower.cpp native_image_argument; same values.)
+            std::vector<std::pair<Stmt *, ImageChain>> closures;
+            number_native_closures(f->code->body, closures);
+            for (size_t k = 0; k < closures.size(); ++k) {
+                std::unique_ptr<FilterCode> sub(new FilterCode());
+                sub->filter = f->module.main;
+                Importer imps(f->module, *sub, shared);
+                imps.block(main_code->first_stmt, sub->body, nullptr);
+                imps.find_result();
+                propagate_types(*sub);
+                std::vector<std::pair<Stmt *, ImageChain>> again;
+                number_native_closures(sub->body, again);
+                if (again.size() != closures.size()) throw CompileError("internal: closure numbering differs between imports");
+                Stmt *def = again[k].first;
+                if (def->parent) throw CompileError("a filter closure passed to a native filter inside a conditional or a loop is not supported");
+                Gen g(*sub);
+                Primary rx, ry;
+                emit_closure_render_coordinates(g, again[k].second, again[k].second.factors.empty(), &rx, &ry);
+                Rhs call;
+                call.kind = Rhs::FilterCall;
+                call.filter = def->rhs.filter;
+                call.args = def->rhs.args;
+                call.args.push_back(rx);
+                call.args.push_back(ry);
+                call.args.push_back(Primary::F(0.0f));
+                CompVar *tv = g.temp(Ty::Tuple);
+                tv->tuple_len = 4;
+                g.assign(tv, call);
+                for (int i = 0; i < 4; ++i) {
+                    CompVar *c = g.temp(Ty::Float);
+                    sub->result[i] = g.assign_op(c, "TUPLE_NTH", {g.P(tv), Primary::I(i)});
+                }
+                for (auto &kv : shared.filters)
+                    if (kv.second == def->rhs.filter && std::find(shared.called.begin(), shared.called.end(), kv.first) == shared.called.end())
+                        shared.called.push_back(kv.first);
+                f->code->closure_renders.push_back(std::move(sub));
+            }
             // filter_$name bodies of the filters called at run time, and of those they call (backends/cc.c:189-196
             // prints every filter's code as a function; only the called ones are needed here)
             for (size_t ci = 0; ci < shared.called.size(); ++ci) {

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 
@@ -322,11 +323,32 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
         fc.filter = ex.filter(m.main);
         export_code(*code, fc);
         std::deque<mmabi_filter_code_t> fn_codes;
+        std::vector<const Filter *> have;
         for (auto &fn : code->functions) {
             fn_codes.emplace_back();
             fn_codes.back().filter = ex.filter(fn->filter);
             export_code(*fn, fn_codes.back());
+            have.push_back(fn->filter);
         }
+        // the reference hands the backend a code for *every* filter of the module (compiler_compile_filters); the ones a
+        // backend can need besides the called ones are the filters whose closures are made in the main code (a closure
+        // image given to a native filter is rendered by its own filter's code)
+        std::vector<std::unique_ptr<FilterCode>> closure_codes;
+        std::function<void(const Block &)> find_closures = [&](const Block &b) {
+            for (const Stmt *st : b) {
+                if (st->kind == Stmt::Assign && st->rhs.kind == Rhs::Closure && st->rhs.filter->kind == Filter::MathMap &&
+                    st->rhs.filter != m.main && std::find(have.begin(), have.end(), st->rhs.filter) == have.end()) {
+                    have.push_back(st->rhs.filter);
+                    closure_codes.push_back(lower_function(m, const_cast<Filter *>(st->rhs.filter)));
+                    fn_codes.emplace_back();
+                    fn_codes.back().filter = ex.filter(st->rhs.filter);
+                    export_code(*closure_codes.back(), fn_codes.back());
+                }
+                if (st->kind == Stmt::If) { find_closures(st->then_); find_closures(st->else_); }
+                if (st->kind == Stmt::While) find_closures(st->body);
+            }
+        };
+        find_closures(code->body);
 
         std::vector<mmabi_filter_code_t *> codes(flist.size(), nullptr);
         for (size_t i = 0; i < flist.size(); ++i) {

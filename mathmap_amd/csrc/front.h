@@ -128,5 +128,9 @@ void parse_module(Module &m, const std::string &source);
 // `uv_consts` (optional): user-value index -> literal to bake in instead of the run-time
 // USERVAL_*_ACCESS read (user-value specialisation, specialize.cpp).
 std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<int, Primary> *uv_consts = nullptr);
+// The body of filter_$name (new_template.c.in:375-422): user values read from the call's argument block, x y t as
+// internals.  What lower_filter puts into FilterCode::functions; also what the reference hands a backend as the
+// filter_code of a filter other than the main one (tests/libmathmap_hip_selftest exports it in that role).
+std::unique_ptr<FilterCode> lower_function(Module &m, Filter *f);
 
 }  // namespace mm

@@ -196,4 +196,72 @@ void gen_if(const Cond &c, const std::function<void()> &then_, const std::functi
     g.end_if();
 }
 
+ImageChain resolve_image_chain(Value *v) {
+    ImageChain c;
+    bool stripped = false;
+    for (int guard = 0; guard < 1000 && v; ++guard) {
+        Stmt *d = v->def;
+        if (!d || d->kind != Stmt::Assign) { c.base = v->index < 0 ? ImageChain::Unknown : ImageChain::Runtime; return c; }
+        const Rhs &r = d->rhs;
+        if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val) { v = r.prim.value; continue; }
+        if (r.kind == Rhs::Op && std::string(r.op->cname) == "STRIP_RESIZE" && r.args[0].kind == Primary::Val) {
+            stripped = true;
+            v = r.args[0].value;
+            continue;
+        }
+        if (r.kind == Rhs::Op && std::string(r.op->cname) == "RESIZE_IMAGE" && r.args[0].kind == Primary::Val) {
+            if (!stripped) c.factors.push_back({r.args[1], r.args[2]});
+            stripped = false;   // a strip only removes the one resize directly below it
+            v = r.args[0].value;
+            continue;
+        }
+        if (r.kind == Rhs::Closure && r.filter->kind == Filter::MathMap) {
+            c.base = ImageChain::MathMapClosure;
+            c.closure_def = d;
+            return c;
+        }
+        c.base = ImageChain::Runtime;
+        return c;
+    }
+    c.base = ImageChain::Runtime;
+    return c;
+}
+
+void emit_closure_render_coordinates(Gen &g, const ImageChain &ch, bool raw, Primary *xo, Primary *yo) {
+    if (raw || ch.factors.empty()) {
+        CompVar *x = g.temp(), *y = g.temp();
+        g.assign(x, Rhs::Int("x"));
+        g.assign(y, Rhs::Int("y"));
+        *xo = g.P(x);
+        *yo = g.P(y);
+        return;
+    }
+    // floatmap.c:39-41: ax = bx = (float)(w - 1) / 2.0, by = (float)(h - 1) / 2.0, ay = by * -1.0
+    CompVar *w = g.temp(), *h = g.temp(), *w1 = g.temp(), *h1 = g.temp(), *ax = g.temp(), *by = g.temp(), *ay = g.temp();
+    CompVar *cf = g.temp(), *rf = g.temp(), *dx = g.temp(), *dy = g.temp(), *fx = g.temp(), *fy = g.temp();
+    g.assign(w, Rhs::Int("__renderPixelW"));
+    g.assign(h, Rhs::Int("__renderPixelH"));
+    g.assign_op(w1, "SUB", {g.P(w), Primary::I(1)});
+    g.assign_op(h1, "SUB", {g.P(h), Primary::I(1)});
+    g.assign_op(ax, "DIV", {g.P(w1), Primary::I(2)});
+    g.assign_op(by, "DIV", {g.P(h1), Primary::I(2)});
+    g.assign_op(ay, "NEG", {g.P(by)});
+    g.assign(cf, Rhs::Int("__colF"));                // (float)column of the pixel in the frame
+    g.assign(rf, Rhs::Int("__rowF"));
+    g.assign_op(dx, "SUB", {g.P(cf), g.P(ax)});
+    g.assign_op(dy, "SUB", {g.P(rf), g.P(by)});
+    g.assign_op(fx, "DIV", {g.P(dx), g.P(ax)});
+    g.assign_op(fy, "DIV", {g.P(dy), g.P(ay)});
+    CompVar *x = fx, *y = fy;
+    for (auto &fac : ch.factors) {                    // opmacros.h:203-207, one wrapper per resize
+        CompVar *nx = g.temp(), *ny = g.temp();
+        g.assign_op(nx, "MUL", {g.P(x), fac.first});
+        g.assign_op(ny, "MUL", {g.P(y), fac.second});
+        x = nx;
+        y = ny;
+    }
+    *xo = g.P(x);
+    *yo = g.P(y);
+}
+
 }  // namespace mm

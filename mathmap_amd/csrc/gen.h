@@ -52,6 +52,19 @@ class Gen {
     static void rewrite_block(Block &b, Value *from, Value *to);
 };
 
+// An image value followed through copies, STRIP_RESIZE and RESIZE_IMAGE down to what it is made of
+// (lower.cpp, abi_backend.cpp: closure images handed to native filters).
+struct ImageChain {
+    enum Base { Unknown, MathMapClosure, Runtime } base = Unknown;
+    Stmt *closure_def = nullptr;
+    std::vector<std::pair<Primary, Primary>> factors;   // resize factors applied on top of the base, outermost first
+};
+ImageChain resolve_image_chain(Value *v);
+// The coordinates at which render_image evaluates a closure for the pixel being computed: the pixel's own raw x, y
+// (its closure branch, builtins.c:273-298) or, for a closure that still wears resize wrappers, the float arithmetic
+// of the drawable branch with the wrappers' factors applied (builtins.c:303-343, opmacros.h:203-207).
+void emit_closure_render_coordinates(Gen &g, const ImageChain &ch, bool raw, Primary *x, Primary *y);
+
 // ---------------------------------------------------------------------------
 // Tiny expression DSL for builtin generators: an `E` is a scalar compvar; the
 // overloaded operators emit the corresponding IR op into a fresh temporary.

@@ -28,13 +28,6 @@ struct Env {
     Env *parent = nullptr;
 };
 
-struct ImageChain {
-    // resolved base of an image value plus the resize factors applied on top of it
-    enum Base { Unknown, MathMapClosure, Runtime } base = Unknown;
-    Stmt *closure_def = nullptr;
-    std::vector<std::pair<Primary, Primary>> factors;   // outermost first
-};
-
 class Lowerer {
    public:
     Lowerer(Module &m, FilterCode &code) : m_(m), code_(code), g_(code) {}
@@ -86,7 +79,6 @@ class Lowerer {
     void find_vector_variables(AstNode *n);
     CompVar *gen_tree_vector(AstNode *tree, CompVar **dest, bool alloced);
     void to_float(CompVar *dst, CompVar *src) { g_.assign_op(dst, "INT2FLOAT", {g_.P(src)}); }
-    ImageChain resolve_image(Value *v);
     void alloc_var(Variable *v);
     void reset_vars(FilterVars *fv);
 };
@@ -367,39 +359,6 @@ bool Lowerer::const_value(const Value *v, Primary *out, int depth) {
     return fold_constant_op(r.op, cs, *out);
 }
 
-// Follows an image value's definitions through copies, STRIP_RESIZE and
-// RESIZE_IMAGE down to a closure or a run-time image.
-ImageChain Lowerer::resolve_image(Value *v) {
-    ImageChain c;
-    bool stripped = false;
-    for (int guard = 0; guard < 1000 && v; ++guard) {
-        Stmt *d = v->def;
-        if (!d || d->kind != Stmt::Assign) { c.base = v->index < 0 ? ImageChain::Unknown : ImageChain::Runtime; return c; }
-        const Rhs &r = d->rhs;
-        if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val) { v = r.prim.value; continue; }
-        if (r.kind == Rhs::Op && std::string(r.op->cname) == "STRIP_RESIZE" && r.args[0].kind == Primary::Val) {
-            stripped = true;
-            v = r.args[0].value;
-            continue;
-        }
-        if (r.kind == Rhs::Op && std::string(r.op->cname) == "RESIZE_IMAGE" && r.args[0].kind == Primary::Val) {
-            if (!stripped) c.factors.push_back({r.args[1], r.args[2]});
-            stripped = false;   // a strip only removes the one resize directly below it
-            v = r.args[0].value;
-            continue;
-        }
-        if (r.kind == Rhs::Closure && r.filter->kind == Filter::MathMap) {
-            c.base = ImageChain::MathMapClosure;
-            c.closure_def = d;
-            return c;
-        }
-        c.base = ImageChain::Runtime;
-        return c;
-    }
-    c.base = ImageChain::Runtime;
-    return c;
-}
-
 // An image argument of a native filter / of render(): when it is a MathMap closure, the native filter
 // renders it first -- render_image's closure branch (builtins.c:267-302) launches the closure's own
 // calc_lines over the whole frame with floatmap = 1 at frame 0, t = 0.0.  The closure gets a number;
@@ -413,7 +372,7 @@ ImageChain Lowerer::resolve_image(Value *v) {
 // ORIG_VAL(fx, fy, image, 0.0) with fx = ((float)x - bx) / ax in float arithmetic, the resize factors
 // applied by the macro (opmacros.h:203-207).  Same result type, slightly different coordinates.
 void Lowerer::native_image_argument(CompVar *image, bool stripped) {
-    ImageChain ch = resolve_image(image->current);
+    ImageChain ch = resolve_image_chain(image->current);
     if (ch.base != ImageChain::MathMapClosure) return;
     Stmt *def = ch.closure_def;
     if (in_target_body_) return;     // (a closure rendered for a native filter may not feed native filters itself)
@@ -421,37 +380,10 @@ void Lowerer::native_image_argument(CompVar *image, bool stripped) {
     if (def->closure_id != render_target_ || target_done_) return;
     if (while_depth_ > 0) throw CompileError("a filter closure passed to a native filter inside a loop is not supported");
     std::vector<Primary> cargs = def->rhs.args;
-    if (stripped || ch.factors.empty()) {
-        cargs.push_back(Primary::V(internal_value("x", false)));
-        cargs.push_back(Primary::V(internal_value("y", false)));
-    } else {
-        // floatmap.c:39-41: ax = bx = (float)(w - 1) / 2.0, by = (float)(h - 1) / 2.0, ay = by * -1.0
-        CompVar *w = g_.temp(), *h = g_.temp(), *w1 = g_.temp(), *h1 = g_.temp(), *ax = g_.temp(), *by = g_.temp(), *ay = g_.temp();
-        CompVar *cf = g_.temp(), *rf = g_.temp(), *dx = g_.temp(), *dy = g_.temp(), *fx = g_.temp(), *fy = g_.temp();
-        g_.assign(w, Rhs::Int("__renderPixelW"));
-        g_.assign(h, Rhs::Int("__renderPixelH"));
-        g_.assign_op(w1, "SUB", {g_.P(w), Primary::I(1)});
-        g_.assign_op(h1, "SUB", {g_.P(h), Primary::I(1)});
-        g_.assign_op(ax, "DIV", {g_.P(w1), Primary::I(2)});
-        g_.assign_op(by, "DIV", {g_.P(h1), Primary::I(2)});
-        g_.assign_op(ay, "NEG", {g_.P(by)});
-        g_.assign(cf, Rhs::Int("__colF"));                // (float)column of the pixel in the frame
-        g_.assign(rf, Rhs::Int("__rowF"));
-        g_.assign_op(dx, "SUB", {g_.P(cf), g_.P(ax)});
-        g_.assign_op(dy, "SUB", {g_.P(rf), g_.P(by)});
-        g_.assign_op(fx, "DIV", {g_.P(dx), g_.P(ax)});
-        g_.assign_op(fy, "DIV", {g_.P(dy), g_.P(ay)});
-        CompVar *x = fx, *y = fy;
-        for (auto &fac : ch.factors) {                    // opmacros.h:203-207, one wrapper per resize
-            CompVar *nx = g_.temp(), *ny = g_.temp();
-            g_.assign_op(nx, "MUL", {g_.P(x), fac.first});
-            g_.assign_op(ny, "MUL", {g_.P(y), fac.second});
-            x = nx;
-            y = ny;
-        }
-        cargs.push_back(g_.P(x));
-        cargs.push_back(g_.P(y));
-    }
+    Primary rx, ry;
+    emit_closure_render_coordinates(g_, ch, stripped, &rx, &ry);
+    cargs.push_back(rx);
+    cargs.push_back(ry);
     cargs.push_back(Primary::F(0.0f));                     // frame 0 / t = 0.0 in both branches
     CompVar *res[4];
     in_target_body_ = true;          // numbering must not depend on which closure is the target
@@ -515,7 +447,7 @@ void Lowerer::gen_func(AstNode *n, CompVar **dest, bool alloced) {
     }
     // Application of a MathMap closure: inline the callee at the sampled position.
     if (n->entry->id == "origValXY") {
-        ImageChain chain = resolve_image(args[2][0]->current);
+        ImageChain chain = resolve_image_chain(args[2][0]->current);
         if (chain.base == ImageChain::MathMapClosure) {
             CompVar *x = args[0][0], *y = args[0][1];
             for (auto &fac : chain.factors) {   // compopt/resize.c:29-98
@@ -808,6 +740,16 @@ static std::unique_ptr<FilterCode> lower_filter_impl(Module &m, Filter *f, const
         code->functions.push_back(std::move(fn));
     }
     return code;
+}
+
+std::unique_ptr<FilterCode> lower_function(Module &m, Filter *f) {
+    if (f->kind != Filter::MathMap) throw CompileError("cannot lower a native filter");
+    std::unique_ptr<FilterCode> fn(new FilterCode());
+    fn->filter = f;
+    Lowerer lf(m, *fn);
+    lf.run_function(f);
+    propagate_types(*fn);
+    return fn;
 }
 
 std::unique_ptr<FilterCode> lower_filter(Module &m, Filter *f, const std::map<int, Primary> *uv_consts) {

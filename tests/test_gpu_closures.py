@@ -95,6 +95,25 @@ def test_closure_arguments_are_values_of_the_current_frame_and_its_body_runs_at_
     assert np.array_equal(i2.render(t=0.9, frame=3), got)
 
 
+@pytest.mark.parametrize("name", ["blur", "render", "two", "timed_arg"])
+def test_closure_images_for_native_filters_through_the_reference_abi(name):
+    """The same through gen_and_load_hip_code: the importer finds the closure images that reach native filters in the
+    reference-layout IR, builds each one's render code from the main filter's code plus a call of the closure's own
+    filter_code (abi_backend.cpp), and calc_lines must deliver the standalone tier's frame byte for byte."""
+    import ctypes as C
+    from mathmap_amd._lib import selftest_lib
+    src = {"blur": BLUR_OF_CLOSURE, "render": RENDER_OF_CLOSURE, "two": TWO_CLOSURES, "timed_arg": TIMED_ARG}[name]
+    w, h = 192, 128
+    img = np.ascontiguousarray(W.synthetic_image(w, h, seed=3))
+    flt, inv = make_invocation(src, w, h, {}, {"in": img})
+    want = inv.render(t=0.25)
+    got = np.zeros((h, w, 4), np.uint8)
+    rc = selftest_lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p), w, h, 3, w, h, 0.25, 2,
+                                                     got.ctypes.data_as(C.c_void_p))
+    assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
+    assert np.array_equal(got, want), stats(got, want)
+
+
 def test_native_filter_on_a_recursive_closure():
     """The closure handed to the blur is a recursive filter whose body ends in an `if` (its result values are exit
     phis of a top-level construct) and calls itself at run time: the closure's render kernel calls the main code's
