@@ -197,6 +197,7 @@ struct Exporter {
                 r->v.tuple.args = primary_arrays.back().data();
                 break;
             }
+            case Rhs::None: break;
             case Rhs::FilterCall: {
                 r->kind = MMABI_RHS_FILTER;
                 r->v.filter.filter = filter(s.filter);
