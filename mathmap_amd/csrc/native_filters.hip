@@ -272,14 +272,25 @@ struct DrawableSrc {
 // coordinates: lines are rows of the window, steps are columns.
 struct PackOut { unsigned char *out; long row_stride; int line_lo, line_hi, k_lo, k_hi; int write_map; };
 
-// new_template.c.in:279-293 for output_bpp 4: CLAMP01 in float, the product in double, the
-// conversion to a byte truncates (mm_store_pixel in mm_device.h).
+// new_template.c.in:279-293 for output_bpp 4: CLAMP01 in float, the product in double, the conversion to a byte
+// truncates: the byte is floor(255 c), exactly what one f32 fma under round-toward-zero leaves in the low mantissa bits
+// of 255 c + 2^23 (mm_pack_rgba8 in mm_device.h has the argument).  Only the single-precision rounding mode is
+// switched (MODE bits 1:0), inside one asm statement; the f64 recurrences around it are not affected.
 __device__ __forceinline__ unsigned pack_rgba8(float4 v) {
-    const unsigned r = (unsigned char)(__builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f) * 255.0);
-    const unsigned g = (unsigned char)(__builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f) * 255.0);
-    const unsigned b = (unsigned char)(__builtin_amdgcn_fmed3f(v.z, 0.0f, 1.0f) * 255.0);
-    const unsigned a = (unsigned char)(__builtin_amdgcn_fmed3f(v.w, 0.0f, 1.0f) * 255.0);
-    return r | (g << 8) | (b << 16) | (a << 24);
+    const float r = __builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f), g = __builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f);
+    const float b = __builtin_amdgcn_fmed3f(v.z, 0.0f, 1.0f), a = __builtin_amdgcn_fmed3f(v.w, 0.0f, 1.0f);
+    unsigned ur, ug, ub, ua;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_fma_f32 %0, %4, %8, %9\n\t"
+                 "v_fma_f32 %1, %5, %8, %9\n\t"
+                 "v_fma_f32 %2, %6, %8, %9\n\t"
+                 "v_fma_f32 %3, %7, %8, %9\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(ur), "=&v"(ug), "=&v"(ub), "=&v"(ua)
+                 : "v"(r), "v"(g), "v"(b), "v"(a), "s"(255.0f), "v"(8388608.0f));
+    const unsigned lo = __builtin_amdgcn_perm(ug, ur, 0x0c0c0400u);      // r | g << 8
+    const unsigned hi = __builtin_amdgcn_perm(ua, ub, 0x0c0c0400u);      // b | a << 8
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
 struct IirState { double s1, s2, s3, s4, v1, v2, v3, v4; };
