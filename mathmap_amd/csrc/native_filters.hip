@@ -255,8 +255,15 @@ struct DrawableSrc {
     __device__ __forceinline__ raw_t at(const raw_t *r, int u) const {
         return *(const raw_t *)((const char *)r + (((unsigned)u * sw + lane) << 2));
     }
-    // TUPLE_FROM_COLOR: (c >> shift & 0xff) / 255.0 == ... * (1.0 / 255.0) for all 256 bytes (enumerated)
-    __device__ __forceinline__ float decode(raw_t c) const { return (float)((double)((c >> shift) & 0xff) * (1.0 / 255.0)); }
+    // TUPLE_FROM_COLOR: (float)((c >> shift & 0xff) / 255.0) -- the correctly rounded quotient k / 255 for all 256 bytes,
+    // and so is one Newton step on the f32 product (q = k r, q' = q + (k - 255 q) r, the residual exact in an fma;
+    // enumerated in tests/test_cpu_suite.py, mm_bytes_to_unit in mm_device.h): three f32 instructions instead of a
+    // conversion to f64, an f64 product and a conversion back, on a wave that has the SIMD to itself
+    __device__ __forceinline__ float decode(raw_t c) const {
+        const float k = (float)((c >> shift) & 0xff), r = 1.0f / 255.0f;
+        const float q = k * r;
+        return __builtin_fmaf(__builtin_fmaf(-255.0f, q, k), r, q);
+    }
     __device__ __forceinline__ DrawableSrc for_lane(long L) const { return DrawableSrc{p, sw, (unsigned)(L >> 2), 24 - 8 * (int)(L & 3)}; }
 };
 
