@@ -17,7 +17,7 @@
 //                      pairs of values in lockstep (two interleaved instruction streams), see pair_stmts
 //
 // Environment hooks for experiments (never needed for correct operation): MMHIP_UNROLL, MMHIP_TILE_W,
-// MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU, MMHIP_NO_FETCHED_RESULT, MMHIP_NO_SAME_TAPS, MMHIP_NO_OUTSIDE_SHORTCUT,
+// MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU, MMHIP_NO_FETCHED_RESULT, MMHIP_NO_SAME_TAPS, MMHIP_NO_OUTSIDE_SHORTCUT, MMHIP_PAIR_MASKS,
 // MMHIP_MAX_CALL_DEPTH here; MMHIP_NO_CSE in passes.cpp; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE, MMHIP_CACHE_DIR,
 // MMHIP_SOURCE_OVERRIDE in runtime.cpp.
 //
@@ -657,9 +657,9 @@ struct Generator {
 
     // operand as a 2-vector of the wanted type (mm_vf / mm_vi broadcast scalars and convert int -> float)
     std::string pbool(const Primary &p) {        // operand as mm_bb
-        if (p.kind == Primary::IntConst) return p.i ? "mm_bb{true, true}" : "mm_bb{false, false}";
-        if (p.kind == Primary::Val && p.value->index < 0) return "mm_bb{false, false}";
-        if (pair_uniform.count(p.value)) return "mm_bb{(bool)u" + vname(p.value) + ", (bool)u" + vname(p.value) + "}";
+        if (p.kind == Primary::IntConst) return p.i ? "mm_bu(true)" : "mm_bu(false)";
+        if (p.kind == Primary::Val && p.value->index < 0) return "mm_bu(false)";
+        if (pair_uniform.count(p.value)) return "mm_bu((bool)u" + vname(p.value) + ")";
         if (pair_bools.count(p.value)) return vname(p.value);
         return "mm_tob(" + pprim(p, Ty::Int) + ")";
     }
@@ -698,7 +698,7 @@ struct Generator {
                 const std::string ex = comp(r.args[0], "x") + " " + op + " " + comp(r.args[1], "x");
                 const std::string ey = comp(r.args[0], "y") + " " + op + " " + comp(r.args[1], "y");
                 if (op[0] == '<' || op[0] == '=') {
-                    const std::string b = "mm_bb{" + ex + ", " + ey + "}";
+                    const std::string b = "mm_bl(" + ex + ", " + ey + ")";
                     return as_bool ? b : "mm_vi(" + b + ")";
                 }
                 return "mm_pf{(float)(" + ex + "), (float)(" + ey + ")}";
@@ -1056,6 +1056,7 @@ struct Generator {
         if (tw != 8 && tw != 16 && tw != 32 && tw != 64 && tw != 128 && tw != 256) tw = auto_tile_w();
         ks.tile_w = tw;
         ks.tile_h = 256 / tw;
+        if (const char *e = getenv("MMHIP_PAIR_MASKS")) out << "#define MM_PAIR_MASKS " << atoi(e) << "\n";
         if (getenv("MMHIP_NO_SAME_TAPS")) out << "#define MM_NO_SAME_TAPS 1\n";      // A/B switches
         if (getenv("MMHIP_NO_OUTSIDE_SHORTCUT")) out << "#define MM_NO_OUTSIDE_SHORTCUT 1\n";
         out << "#define MM_INTERSAMPLE " << opt.intersample << "\n";
@@ -1208,7 +1209,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                     << I << "  const int row_a = rl_a < A.num_rows ? rl_a : A.num_rows - 1, row_b = rl_b < A.num_rows ? rl_b : A.num_rows - 1;\n"
                     << I << "  const mm_pf mm_y2 = {A.ytab[row_a], A.ytab[row_b]};    // CALC_VIRTUAL_Y per row, by the prologue\n";
                 pair_decls(pix_defs, I + "  ");
-                pair_stmts(code.body, I + "  ", "mm_bb{true, true}");
+                pair_stmts(code.body, I + "  ", "mm_bu(true)");
                 out << I << "  mm_tup<4> mm_ra, mm_rb;\n";
                 for (int i = 0; i < 4; ++i) {
                     const std::string v = pprim(Primary::V(code.result[i]), Ty::Float);
