@@ -1150,7 +1150,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
   const int xcd = bid & 7, q = bid >> 3;
   const int per = nwg >> 3, rem = nwg & 7;
   const int swz = xcd * per + (xcd < rem ? xcd : rem) + q;
-  const int tile_y = swz / tiles_x, tile_x = swz - tile_y * tiles_x;
+  const int tile_y = A.tiles_magic ? (int)__umulhi((unsigned)swz, A.tiles_magic) : swz / tiles_x, tile_x = swz - tile_y * tiles_x;
   const int col = tile_x * MM_TILE_W + (threadIdx.x % MM_TILE_W);
   // a workgroup owns MM_TILE_W x (MM_TILE_H * A.ppt) pixels; each work-item walks A.ppt rows
   // MM_TILE_H apart, so wave start-up (kernarg / descriptor loads, tile arithmetic) and the

@@ -87,6 +87,8 @@ struct mm_args {
     // column instead of once per pixel.
     float *xtab;
     float *ytab;
+    unsigned tiles_magic;             // workgroup id / tile columns by multiply-high (mm_host_abi.h), 0: divide
+    unsigned pad_;
 };
 
 // ---- op macros (opmacros.h:30-47) --------------------------------------------------

@@ -45,7 +45,17 @@ struct HArgs {
     int ppt;
     float *xtab;
     float *ytab;
+    uint32_t tiles_magic;     // ceil(2^32 / tiles_x) when workgroup id / tiles_x is exact by multiply-high, else 0
+    uint32_t pad_;
 };
+
+// workgroup id -> (tile row, tile column) is one division by the number of tile columns per work-item start-up; a
+// multiply-high by ceil(2^32 / d) gives the same quotient for every n with n * d < 2^32 (the error of the product is
+// below n / 2^32 < 1 / d, the smallest distance of n / d to the next integer)
+static inline uint32_t tile_division_magic(long tiles_x, long nwg) {
+    if (tiles_x < 2 || nwg * tiles_x >= (1L << 32)) return 0;
+    return (uint32_t)(((1UL << 32) + (unsigned long)tiles_x - 1) / (unsigned long)tiles_x);
+}
 
 struct HNativeArg { int kind; int i; float f; HImage img; };
 struct HNativeRec { int executed; int index; int nargs; int pad; HNativeArg args[4]; };
@@ -53,6 +63,6 @@ struct HNativeRec { int executed; int index; int nargs; int pad; HNativeArg args
 static_assert(sizeof(HImage) == 24, "mm_image layout");
 static_assert(sizeof(HImageDesc) == 56, "mm_image_desc layout");
 static_assert(sizeof(HNativeArg) == 36, "mm_narg_t layout");
-static_assert(sizeof(HArgs) == 152, "mm_args layout");
+static_assert(sizeof(HArgs) == 160, "mm_args layout");
 
 }  // namespace mm

@@ -671,6 +671,7 @@ static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const
     const int tiles_x = (w + ck.ks.tile_w - 1) / ck.ks.tile_w;
     a.ppt = rows_per_item(ck.ks, tiles_x, h);
     const int tiles_y = (h + ck.ks.tile_h * a.ppt - 1) / (ck.ks.tile_h * a.ppt);
+    a.tiles_magic = tile_division_magic(tiles_x, (long)tiles_x * tiles_y);
     char *xy = st.d_xy;
     void *params[] = {&a, &xy};
     const int n = std::max(w, h);
@@ -989,6 +990,7 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
         HArgs key = a;
         key.out = nullptr;
         key.row_stride = key.output_bpp = key.floatmap = key.ppt = 0;
+        key.tiles_magic = 0;
         if (!f->ks.prologue_uses_time) { key.t = 0.0f; key.frame = 0; }
         const bool fresh = f->ks.natives.empty() && inv->pro_filter == f && inv->pro_stream == (void *)s &&
                            inv->pro_generation == inv->table_generation &&
@@ -1008,6 +1010,7 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     int tiles_y = (a.num_rows + f->ks.tile_h * a.ppt - 1) / (f->ks.tile_h * a.ppt);
     long nwg = (long)tiles_x * tiles_y;
     if (nwg > 0x7fffffffL) return fail("region too large for one launch");
+    a.tiles_magic = tile_division_magic(tiles_x, nwg);
     if (inv->timing) {
         if (next_event_pair(inv) != 0) return -1;
         HIP_TRY(hipEventRecord(inv->ev0, s));

@@ -208,6 +208,27 @@ def test_userval_specialisation_preserves_results_on_cpu(name, uv):
     assert np.array_equal(a, b), np.abs(a.astype(int) - b.astype(int)).max()
 
 
+def test_tile_division_by_multiply_high_is_exact_where_it_is_used():
+    """mm_host_abi.h tile_division_magic: workgroup id / tile columns as umulhi(id, ceil(2^32 / d)), used only when
+    nwg * d < 2^32.  Restated here and compared with integer division for every id of small launches and for the ids
+    around every multiple of d of launches at the bound."""
+    def magic(d, nwg):
+        return 0 if d < 2 or nwg * d >= 1 << 32 else ((1 << 32) + d - 1) // d
+    rng = np.random.default_rng(7)
+    for d in [2, 3, 5, 7, 16, 17, 127, 128, 129, 511, 512, 513, 1000, 1024, 4095, 4096, 65535] + list(rng.integers(2, 70000, 40)):
+        d = int(d)
+        nwg = min((1 << 32) // d - 1, 1 << 31)
+        m = magic(d, nwg)
+        assert m and magic(d, (1 << 32) // d + 1) == 0
+        if nwg <= 1 << 20:
+            ids = np.arange(nwg, dtype=np.uint64)
+        else:
+            k = np.unique(np.concatenate([rng.integers(0, nwg // d + 1, 4000), [0, 1, nwg // d - 1, nwg // d]])).astype(np.uint64)
+            ids = np.unique(np.concatenate([k * d + off for off in (0, 1, d - 1, d // 2)] + [np.array([nwg - 1], np.uint64)]))
+            ids = ids[ids < nwg]
+        assert np.array_equal((ids * np.uint64(m)) >> np.uint64(32), ids // np.uint64(d)), d
+
+
 def test_closure_render_takes_arguments_at_the_current_time_and_runs_its_body_at_t_zero():
     """render_image's closure branch (builtins.c:273-298) on the oracle: the closure's calc_lines runs on a frame with
     t = 0.0 and frame = 0, its arguments are what the main filter's code computed at the current t."""
