@@ -438,6 +438,31 @@ def test_byte_to_float_identity():
     assert np.array_equal((c / 255.0).astype(np.float32), (c * (1.0 / 255.0)).astype(np.float32))
 
 
+def test_unit_of_a_byte_packs_back_to_that_byte():
+    """mm_store_fetched_pixel (mm_device.h): a channel that holds RN(k / 255) for a byte k is packed by the template's
+    (unsigned char)(c * 255.0) -- a double product, truncated -- back to k, for all 256 bytes; so a fetched pixel that
+    goes to the output unchanged can be stored from the fetch's rounded byte sums."""
+    k = np.arange(256)
+    q = (k.astype(np.float64) * (1.0 / 255.0)).astype(np.float32)
+    assert np.array_equal(np.trunc(q.astype(np.float64) * 255.0).astype(int), k)
+
+
+def test_round_toward_zero_fma_is_the_templates_pack():
+    """mm_pack_rgba8 (mm_device.h): floor(255 c) for a float c in [0, 1] -- what (unsigned char)(c * 255.0) is, the
+    double product of a float and 255 being exact -- equals the low mantissa byte of the f32 value RTZ(255 c + 2^23).
+    The RTZ fma is emulated exactly (255 c + 2^23 fits a double: 24 + 8 + 24 bits at most ... it does, being below
+    2^24 in magnitude with an ulp of c * 2^-16 >= 2^-165; rounding toward zero to a multiple of 1 is floor)."""
+    rng = np.random.default_rng(3)
+    c = np.concatenate([rng.random(200000, dtype=np.float32), np.float32([0, 1, 0.5, 2 ** -149, 2 ** -126, 1 - 2 ** -24]),
+                        (np.arange(256, dtype=np.float64) / 255.0).astype(np.float32),
+                        np.nextafter((np.arange(1, 256, dtype=np.float64) / 255.0).astype(np.float32), np.float32(0)),
+                        np.nextafter((np.arange(0, 255, dtype=np.float64) / 255.0).astype(np.float32), np.float32(1))])
+    exact = c.astype(np.float64) * 255.0 + 8388608.0           # exact in float64
+    rtz = np.floor(exact)                                     # f32 spacing at 2^23 is 1: round toward zero = floor
+    low_byte = rtz.astype(np.int64) & 0xff
+    assert np.array_equal(low_byte, np.trunc(c.astype(np.float64) * 255.0).astype(np.int64))
+
+
 def test_byte_to_unit_newton_step_identity():
     """mm_bytes_to_unit (mm_device.h): q = k*r, e = fma(-255, q, k), q' = fma(e, r, q) in f32 equals
     (float)((double)k * (1.0/255.0)) for every byte k.  The fmas are emulated exactly: 255*q has at
