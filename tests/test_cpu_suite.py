@@ -463,6 +463,26 @@ def test_round_toward_zero_fma_is_the_templates_pack():
     assert np.array_equal(low_byte, np.trunc(c.astype(np.float64) * 255.0).astype(np.int64))
 
 
+def test_four_equal_taps_interpolate_to_that_byte():
+    """mm_intersample_tuple_cold's shortcuts (mm_device.h): get_orig_val_intersample_pixel's float sums
+    c*p1 + c*p2 + c*p3 + c*p4 (builtins.c:228-247, this order, every operation rounded to float) round to c when all
+    four taps are the byte c, whatever the fractional position -- the weights sum to 1 within 2^-22."""
+    rng = np.random.default_rng(11)
+    n = 20000
+    fx = np.concatenate([rng.random(n, dtype=np.float32), np.float32([0, 0.5, 1 - 2 ** -24, 2 ** -24, 2 ** -30])])
+    fy = np.concatenate([rng.random(n, dtype=np.float32), np.float32([0.5, 0, 1 - 2 ** -24, 1 - 2 ** -24, 2 ** -30])])
+    one = np.float32(1.0)
+    x1, y1 = one - fx, one - fy
+    p1, p2, p3, p4 = x1 * y1, x1 * fy, fx * y1, fx * fy
+    for c in range(256):
+        cf = np.float32(c)
+        sm = cf * p1
+        sm = sm + cf * p2
+        sm = sm + cf * p3
+        sm = sm + cf * p4
+        assert sm.dtype == np.float32 and np.array_equal(np.rint(sm), np.full_like(sm, cf)), c
+
+
 def test_byte_to_unit_newton_step_identity():
     """mm_bytes_to_unit (mm_device.h): q = k*r, e = fma(-255, q, k), q' = fma(e, r, q) in f32 equals
     (float)((double)k * (1.0/255.0)) for every byte k.  The fmas are emulated exactly: 255*q has at
