@@ -17,7 +17,7 @@
 //                      pairs of values in lockstep (two interleaved instruction streams), see pair_stmts
 //
 // Environment hooks for experiments (never needed for correct operation): MMHIP_UNROLL, MMHIP_TILE_W,
-// MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU, MMHIP_NO_FETCHED_RESULT, MMHIP_NO_SAME_TAPS, MMHIP_NO_OUTSIDE_SHORTCUT, MMHIP_PAIR_MASKS,
+// MMHIP_SINGLE_PIXEL, MMHIP_PAIR, MMHIP_PAIR_DEBUG, MMHIP_WAVES_PER_EU, MMHIP_NO_FETCHED_RESULT, MMHIP_NO_SAME_TAPS, MMHIP_NO_OUTSIDE_SHORTCUT, MMHIP_PAIR_MASKS, MMHIP_NT_STORE,
 // MMHIP_MAX_CALL_DEPTH here; MMHIP_NO_CSE in passes.cpp; MMHIP_PPT, MMHIP_HIPRTC_FLAGS, MMHIP_NO_CACHE, MMHIP_CACHE_DIR,
 // MMHIP_SOURCE_OVERRIDE in runtime.cpp.
 //
@@ -1056,6 +1056,7 @@ struct Generator {
         if (tw != 8 && tw != 16 && tw != 32 && tw != 64 && tw != 128 && tw != 256) tw = auto_tile_w();
         ks.tile_w = tw;
         ks.tile_h = 256 / tw;
+        if (const char *e = getenv("MMHIP_NT_STORE")) out << "#define MM_NT_STORE " << atoi(e) << "\n";
         if (const char *e = getenv("MMHIP_PAIR_MASKS")) out << "#define MM_PAIR_MASKS " << atoi(e) << "\n";
         if (getenv("MMHIP_NO_SAME_TAPS")) out << "#define MM_NO_SAME_TAPS 1\n";      // A/B switches
         if (getenv("MMHIP_NO_OUTSIDE_SHORTCUT")) out << "#define MM_NO_OUTSIDE_SHORTCUT 1\n";

@@ -560,9 +560,12 @@ __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *_
             const int k = kb + kk;
             if (line < lines && (FAST || k < n)) {
                 const float4 v = *(const float4 *)&tw[tl * (IIR_U * 4 + 4) + kk * 4];
-                if (po.write_map) *(float4 *)&outT[(line * (long)n + k) * 4] = v;
+                if (po.write_map) {      // written once, read by the next pass long after it has left the caches: non-temporal
+                    typedef float mm_f4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(mm_f4{v.x, v.y, v.z, v.w}, (mm_f4 *)&outT[(line * (long)n + k) * 4]);
+                }
                 if (po.out && line >= po.line_lo && line < po.line_hi && k >= po.k_lo && k < po.k_hi)
-                    *(unsigned *)(po.out + (line - po.line_lo) * po.row_stride + (long)(k - po.k_lo) * 4) = pack_rgba8(v);
+                    __builtin_nontemporal_store(pack_rgba8(v), (unsigned *)(po.out + (line - po.line_lo) * po.row_stride + (long)(k - po.k_lo) * 4));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
