@@ -1056,7 +1056,16 @@ struct Generator {
         if (tw != 8 && tw != 16 && tw != 32 && tw != 64 && tw != 128 && tw != 256) tw = auto_tile_w();
         ks.tile_w = tw;
         ks.tile_h = 256 / tw;
-        if (const char *e = getenv("MMHIP_NT_STORE")) out << "#define MM_NT_STORE " << atoi(e) << "\n";
+        {
+            // non-temporal output stores keep the frame from displacing the *input* in the caches: for kernels that fetch
+            // (a kernel that reads nothing gains nothing, and its 64-byte row segments then reach memory uncombined:
+            // Mandelbrot 8192^2 wrote 347 MB instead of 268 MB in the WRITE_SIZE counter, same time)
+            int stmts = 0, fetches = 0;
+            pixel_stats(code.body, stmts, fetches);
+            int nt = fetches > 0;
+            if (const char *e = getenv("MMHIP_NT_STORE")) nt = atoi(e);
+            out << "#define MM_NT_STORE " << nt << "\n";
+        }
         if (const char *e = getenv("MMHIP_PAIR_MASKS")) out << "#define MM_PAIR_MASKS " << atoi(e) << "\n";
         if (getenv("MMHIP_NO_SAME_TAPS")) out << "#define MM_NO_SAME_TAPS 1\n";      // A/B switches
         if (getenv("MMHIP_NO_OUTSIDE_SHORTCUT")) out << "#define MM_NO_OUTSIDE_SHORTCUT 1\n";

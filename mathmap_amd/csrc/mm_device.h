@@ -775,9 +775,10 @@ MM_DEV float mm_clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f)
 
 // The output frame is written once and not read again by this launch: non-temporal stores keep it from displacing the
 // input in L2 / Infinity Cache (measured at 8192^2: Ident 0.175 -> 0.144 ms, Pond 0.599 -> 0.548, Droste NoTransparency=1 0.93 -> 0.905;
-// Mandelbrot, which reads nothing, unchanged).  MMHIP_NT_STORE=0 switches back.
+// Mandelbrot, which reads nothing, unchanged).  Set per kernel by hipgen.cpp (fetching kernels only); MMHIP_NT_STORE
+// overrides.
 #ifndef MM_NT_STORE
-#define MM_NT_STORE 1
+#define MM_NT_STORE 0
 #endif
 #if MM_NT_STORE
 #define MM_STORE_U32(p, v) __builtin_nontemporal_store((unsigned)(v), (p))
