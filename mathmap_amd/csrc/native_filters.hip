@@ -330,10 +330,11 @@ __device__ __forceinline__ void causal_group(const Src &src, typename Src::raw_t
             }
             if (FAST || (kb > 0 && kb >= s0)) {
                 double *q = ck + (size_t)(kb / IIR_U) * 4 * stride;
-                q[lane] = v1;
-                q[stride + lane] = v2;
-                q[2 * stride + lane] = v3;
-                q[3 * stride + lane] = v4;
+                // (read back by the anticausal kernel after this whole sweep: non-temporal, like the map)
+                __builtin_nontemporal_store(v1, &q[lane]);
+                __builtin_nontemporal_store(v2, &q[stride + lane]);
+                __builtin_nontemporal_store(v3, &q[2 * stride + lane]);
+                __builtin_nontemporal_store(v4, &q[3 * stride + lane]);
             }
             if (FAST || (kb > k0 && kb + IIR_U <= s1)) {
                 // interior block: no edge steps, no bounds; the state "shifts" are register renames
