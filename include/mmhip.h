@@ -68,6 +68,9 @@ mmhip_filter *mmhip_compile(const char *source, const mmhip_options *opts);
 /* like mmhip_compile, with n scalar user values (index, value) baked in as literals */
 mmhip_filter *mmhip_compile_specialized(const char *source, const mmhip_options *opts, int n, const int *indices,
                                         const double *values);
+/* the variant of a compiled filter (from source text or from an IR dump) with n scalar user values baked in:
+   what a render with those values runs when the filter was compiled with specialize_uservals */
+mmhip_filter *mmhip_filter_specialized(const mmhip_filter *f, int n, const int *indices, const double *values);
 /* builds a filter from an IR dump (the JSON of mmhip_filter_ir_json): IR-level entry point */
 mmhip_filter *mmhip_compile_ir_json(const char *ir_json, const mmhip_options *opts);
 void mmhip_filter_free(mmhip_filter *f);
@@ -132,6 +135,9 @@ double mmhip_last_kernel_ms(mmhip_invocation *inv);
 /* Durations of the pixel kernel of all timed launches since the last drain (oldest first, waits
    for the last one): lets a caller queue many launches without a synchronisation per launch. */
 int mmhip_drain_kernel_ms(mmhip_invocation *inv, double *out_ms, int cap);
+/* Durations (ms) of the kernels native filters launched themselves (gaussian_blur's scan kernels) since the last
+   drain, in launch order; names receives a 64-byte label per entry.  Requires mmhip_enable_timing(inv, 1). */
+int mmhip_drain_native_kernel_ms(mmhip_invocation *inv, char *names, double *out_ms, int cap);
 /* Launches of this invocation whose pixels a native filter wrote itself -- a filter like
    examples/Blur/Gaussian Blur.mm, whose pixel is the blurred map sampled at the pixel centre: the
    blur's last kernel packs the output (new_template.c.in:279-293) and the pixel kernel is skipped. */

@@ -33,6 +33,7 @@ SYMBOLS = {
     "mmhip_compile_specialized": (C.c_void_p, [C.c_char_p, C.POINTER(Options), C.c_int, C.POINTER(C.c_int),
                                                C.POINTER(C.c_double)]),
     "mmhip_compile_ir_json": (C.c_void_p, [C.c_char_p, C.POINTER(Options)]),
+    "mmhip_filter_specialized": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmhip_filter_free": (None, [C.c_void_p]),
     "mmhip_filter_name": (C.c_char_p, [C.c_void_p]),
     "mmhip_filter_num_uservals": (C.c_int, [C.c_void_p]),
@@ -52,6 +53,7 @@ SYMBOLS = {
     "mmhip_set_native_row_margin": (C.c_int, [C.c_void_p, C.c_int]),
     "mmhip_drain_kernel_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mmhip_direct_native_launches": (C.c_long, [C.c_void_p]),
+    "mmhip_drain_native_kernel_ms": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]),
     "mmhip_set_curve": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmhip_set_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmhip_set_by_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),

@@ -28,11 +28,16 @@ def _err():
 class Filter:
     """A compiled .mm filter (front-end + IR + generated HIP kernel string)."""
 
-    def __init__(self, source, intersample=True, supersampling=False, edge_x=EDGE_COLOR, edge_y=EDGE_COLOR,
-                 tile_w=0, specialize=False, constants=None, ir_json=None):
+    def __init__(self, source="", intersample=True, supersampling=False, edge_x=EDGE_COLOR, edge_y=EDGE_COLOR,
+                 tile_w=0, specialize=False, constants=None, ir_json=None, _handle=None):
+        """`source`: .mm text; or `ir_json`: an IR dump (mmhip_filter_ir_json_raw / the reference-ABI importer's
+        form) -- the IR-level entry point.  `constants` (name -> number) bakes scalar user values in as literals."""
         self._source = source
         self._kwargs = dict(intersample=intersample, supersampling=supersampling, edge_x=edge_x, edge_y=edge_y,
                             tile_w=tile_w)
+        if _handle is not None:
+            self._h = _handle
+            return
         o = Options()
         lib().mmhip_default_options(C.byref(o))
         o.intersample = 1 if intersample else 0
@@ -42,24 +47,34 @@ class Filter:
         o.specialize_uservals = 1 if specialize else 0
         if ir_json is not None:
             self._h = lib().mmhip_compile_ir_json(ir_json.encode(), C.byref(o))
-        elif constants:
-            # bake scalar user values in as literals (the variant the specialising JIT builds lazily)
-            probe = lib().mmhip_compile(source.encode(), C.byref(o))
-            if not probe:
-                raise MathMapError(_err())
-            names = {}
-            for i in range(lib().mmhip_filter_num_uservals(probe)):
-                info = UservalInfo()
-                lib().mmhip_filter_userval_info(probe, i, C.byref(info))
-                names[info.name.decode()] = i
-            lib().mmhip_filter_free(probe)
-            idx = (C.c_int * len(constants))(*[names[k] for k in constants])
-            val = (C.c_double * len(constants))(*[float(v) for v in constants.values()])
-            self._h = lib().mmhip_compile_specialized(source.encode(), C.byref(o), len(constants), idx, val)
         else:
             self._h = lib().mmhip_compile(source.encode(), C.byref(o))
         if not self._h:
             raise MathMapError(_err())
+        if constants:
+            # bake scalar user values in as literals (the variant the specialising JIT builds lazily)
+            base, self._h = self._h, None
+            try:
+                self._h = self._specialized_handle(base, constants)
+            finally:
+                lib().mmhip_filter_free(base)
+
+    @staticmethod
+    def _specialized_handle(handle, constants):
+        names = {}
+        for i in range(lib().mmhip_filter_num_uservals(handle)):
+            info = UservalInfo()
+            lib().mmhip_filter_userval_info(handle, i, C.byref(info))
+            names[info.name.decode()] = i
+        for k in constants:
+            if k not in names:
+                raise MathMapError("filter has no user value `%s'" % k)
+        idx = (C.c_int * len(constants))(*[names[k] for k in constants])
+        val = (C.c_double * len(constants))(*[float(v) for v in constants.values()])
+        h = lib().mmhip_filter_specialized(handle, len(constants), idx, val)
+        if not h:
+            raise MathMapError(_err())
+        return h
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -110,7 +125,7 @@ class Filter:
         for k, v in (values or {}).items():
             if k in consts:
                 consts[k] = v
-        return Filter(self._source, constants=consts, **self._kwargs)
+        return Filter(self._source, _handle=self._specialized_handle(self._h, consts), **self._kwargs)
 
     @property
     def kernel_source(self):
@@ -237,6 +252,16 @@ class Invocation:
         if n < 0:
             raise MathMapError(_err())
         return [buf[i] for i in range(n)]
+
+    def drain_native_kernel_ms(self, cap=4096):
+        """(label, ms) of every kernel native filters launched themselves since the last drain (gaussian_blur's
+        scan kernels), in launch order."""
+        names = C.create_string_buffer(cap * 64)
+        buf = (C.c_double * cap)()
+        n = lib().mmhip_drain_native_kernel_ms(self._h, names, buf, cap)
+        if n < 0:
+            raise MathMapError(_err())
+        return [(names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode(), buf[i]) for i in range(n)]
 
     def direct_native_launches(self):
         """Launches whose pixels a native filter wrote itself (pixel kernel skipped)."""

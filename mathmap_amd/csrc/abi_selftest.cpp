@@ -16,6 +16,8 @@
 #include "../../include/mmhip.h"
 #include "front.h"
 
+namespace mm { void load_ir_json(Module &mod, FilterCode &code, const char *json); }   // ir_json.cpp
+
 using namespace mm;
 
 namespace {
@@ -292,9 +294,20 @@ const char *mmhip_selftest_error(void) { return g_selftest_err.c_str(); }
 int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint8_t *image, int iw, int ih, int ichannels,
                                  int w, int h, float t, int num_bands, uint8_t *out_rgba) {
     try {
+        // `source`: .mm text, or -- first character '{' -- an IR dump (mmhip_filter_ir_json_raw's form): the
+        // reference's own filters are kept as IR fixtures only (tests/filters.py)
         Module m;
-        parse_module(m, source);
-        std::unique_ptr<FilterCode> code = lower_filter(m, m.main);
+        std::unique_ptr<FilterCode> code;
+        const char *first = source;
+        while (*first == ' ' || *first == '\n' || *first == '\t' || *first == '\r') ++first;
+        const bool from_ir = *first == '{';
+        if (from_ir) {
+            code.reset(new FilterCode());
+            load_ir_json(m, *code, source);
+        } else {
+            parse_module(m, source);
+            code = lower_filter(m, m.main);
+        }
 
         Exporter ex;
         // filter list in module order (native filters first, like register_native_filters
@@ -340,6 +353,7 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
                 if (st->kind == Stmt::Assign && st->rhs.kind == Rhs::Closure && st->rhs.filter->kind == Filter::MathMap &&
                     st->rhs.filter != m.main && std::find(have.begin(), have.end(), st->rhs.filter) == have.end()) {
                     have.push_back(st->rhs.filter);
+                    if (from_ir) throw CompileError("self-test: a closure of filter `" + st->rhs.filter->name + "' needs the filter's source");
                     closure_codes.push_back(lower_function(m, const_cast<Filter *>(st->rhs.filter)));
                     fn_codes.emplace_back();
                     fn_codes.back().filter = ex.filter(st->rhs.filter);

@@ -253,7 +253,12 @@ int main(int argc, char **argv) {
     mmhip_default_options(&opts);
     opts.intersample = antialiasing;
     opts.supersampling = supersampling;
-    mmhip_filter *flt = mmhip_compile(script.c_str(), &opts);
+    // an extension next to the reference's options: a script whose first character is '{' (which no .mm text can
+    // start with) is a compiled filter in the IR dump form of mmhip_filter_ir_json_raw, e.g. the output of another
+    // front-end; everything after compilation is the same
+    size_t first = script.find_first_not_of(" \t\r\n");
+    mmhip_filter *flt = (first != std::string::npos && script[first] == '{') ? mmhip_compile_ir_json(script.c_str(), &opts)
+                                                                             : mmhip_compile(script.c_str(), &opts);
     if (bench_no_backend) return 0;
     if (!flt) { fprintf(stderr, "Error: %s\n", mmhip_last_error()); return 1; }
     if (bench_render_count == 0) return mmhip_filter_jit(flt, 0) < 0 ? 1 : 0;

@@ -27,6 +27,23 @@ struct NativeWorkspace {
     size_t scratch_bytes = 0;
     void *reserve(size_t bytes);
     void release();
+    // per-kernel timing of a native filter's own launches (mmhip_enable_timing): one HIP event pair per
+    // launch on the launch stream, read back by mmhip_drain_native_kernel_ms
+    struct Timed { const char *name; hipEvent_t a, b; };
+    bool timing = false;
+    std::vector<Timed> timed;                   // launches since the last drain, in launch order
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_free;
+    // brackets `launch()` with an event pair when timing is on
+    template <class F> void timed_launch(const char *name, hipStream_t s, F &&launch) {
+        if (!timing || timed.size() >= 4096) { launch(); return; }
+        Timed t{name, nullptr, nullptr};
+        if (!timed_free.empty()) { t.a = timed_free.back().first; t.b = timed_free.back().second; timed_free.pop_back(); }
+        else if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { launch(); return; }
+        (void)hipEventRecord(t.a, s);
+        launch();
+        (void)hipEventRecord(t.b, s);
+        timed.push_back(t);
+    }
     // cached hipFFT plans of the FFT native filters (native_fft.hip)
     void *fft_fwd = nullptr, *fft_inv = nullptr;
     int fft_w = 0, fft_h = 0, fft_batch = 0;

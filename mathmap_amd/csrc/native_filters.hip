@@ -32,6 +32,10 @@ void *NativeWorkspace::reserve(size_t bytes) {
 
 void NativeWorkspace::release() {
     fft_release_plans(*this);
+    for (Timed &t : timed) timed_free.push_back({t.a, t.b});
+    timed.clear();
+    for (auto &p : timed_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    timed_free.clear();
     if (scratch) (void)hipFree(scratch);
     scratch = nullptr;
     scratch_bytes = 0;
@@ -888,12 +892,12 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         const unsigned blocks = g.lane_blocks * segment_count(g);
         if (in.kind == IMG_FLOATMAP || !identity) {
             const MapSrc src{(in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map) + (long)y0 * w * 4, (unsigned)w * 4u, 0u};
-            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1});
+            ws.timed_launch("iir_causal_vertical", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_vertical", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1}); });
         } else {
             const DrawableSrc src{(const uint32_t *)in.data + (long)y0 * in.w, (unsigned)in.w, 0u, 0};
-            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1});
+            ws.timed_launch("iir_causal_vertical", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_vertical", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1}); });
         }
     }
     // horizontal pass (gauss.c:203-252): in mapT the window's rows are the "columns"; transposing again
@@ -912,12 +916,12 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         }
         if (in.kind == IMG_FLOATMAP) {
             const MapSrc src{mapT, (unsigned)hn * 4u, 0u};
-            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po);
+            ws.timed_launch("iir_causal_horizontal", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_horizontal", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po); });
         } else {      // the first pass read bytes: its output is finite
             const FiniteMapSrc src{mapT, (unsigned)hn * 4u, 0u};
-            k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c);
-            k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po);
+            ws.timed_launch("iir_causal_horizontal", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_horizontal", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po); });
         }
     }
     if (hipGetLastError() != hipSuccess) { *err = "gaussian_blur: kernel launch failed"; return -1; }

@@ -559,7 +559,26 @@ int mmhip_set_sampling_offset(mmhip_invocation *inv, float ox, float oy) {
 
 int mmhip_enable_timing(mmhip_invocation *inv, int on) {
     inv->timing = on != 0;
+    inv->ws.timing = on != 0;
     return 0;
+}
+
+// Durations (ms) of the native filters' own kernels (gaussian_blur: its four scan kernels) launched since the last
+// drain, in launch order; names[i * 64 ...] receives the kernel's label.  Waits for the last of them.
+int mmhip_drain_native_kernel_ms(mmhip_invocation *inv, char *names, double *out_ms, int cap) {
+    auto &tm = inv->ws.timed;
+    if (!tm.empty() && hipEventSynchronize(tm.back().b) != hipSuccess) return fail("event sync failed");
+    int n = 0;
+    for (auto &t : tm) {
+        float ms = 0;
+        if (n < cap && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            snprintf(names + (size_t)n * 64, 64, "%s", t.name);
+            out_ms[n++] = ms;
+        }
+        inv->ws.timed_free.push_back({t.a, t.b});
+    }
+    tm.clear();
+    return n;
 }
 
 // The next event pair for a timed launch (grown on demand, wraps after 4096 pending launches).
@@ -872,6 +891,22 @@ static mmhip_filter *compile_ir_specialized(const mmhip_filter *f, const std::ma
         return nullptr;
     }
     return sp;
+}
+
+// The variant of a compiled filter with n scalar user values (index, value) baked in as literals: what
+// active_filter() builds lazily for a value set, for filters of either origin (source text or IR dump).
+extern "C" mmhip_filter *mmhip_filter_specialized(const mmhip_filter *f, int n, const int *indices, const double *values) {
+    std::map<int, Primary> consts;
+    const auto &uvs = f->module.main->uservals;
+    for (int i = 0; i < n; ++i) {
+        if (indices[i] < 0 || indices[i] >= (int)uvs.size()) { g_err = "user value index out of range"; return nullptr; }
+        const UservalInfo &u = uvs[indices[i]];
+        if (u.kind == UvKind::Float) consts[u.index] = Primary::F((float)values[i]);
+        else if (u.kind == UvKind::Int || u.kind == UvKind::Bool) consts[u.index] = Primary::I((int)values[i]);
+    }
+    mmhip_options o = f->opts;
+    o.specialize_uservals = 0;
+    return f->source.empty() ? compile_ir_specialized(f, consts) : compile_source(f->source.c_str(), &o, &consts);
 }
 
 // The kernel set to launch: the generic filter, or -- with options.specialize_uservals -- a

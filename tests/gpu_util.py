@@ -14,7 +14,9 @@ def stats(a, b):
 
 
 def make_invocation(src, w, h, uservals=None, images=None, **opts):
-    flt = mm.Filter(src, **opts)
+    """`src`: .mm text or the name of a filter of tests/filters.py."""
+    from tests import filters as F
+    flt = F.load(src, **opts) if src in F.NAMES else mm.Filter(src, **opts)
     inv = flt.invoke(w, h)
     for k, v in (uservals or {}).items():
         inv.set(k, v)

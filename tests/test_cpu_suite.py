@@ -10,14 +10,15 @@ import numpy as np
 import pytest
 
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
 from mathmap_amd._lib import BACKEND_SYMBOLS, LIB_PATH, SYMBOLS, lib
 from oracle.ccgen import CpuFilter
+from tests import filters as F
 from tests.conftest import REFERENCE, ROOT, load_png_rgb
 
 
 def oracle_render(src, uv=None, image=None, w=256, h=256, t=0.0, intersample=True):
-    flt = mm.Filter(src)
+    """`src`: .mm text, or a compiled Filter (the reference's filters come from IR fixtures, tests/filters.py)."""
+    flt = src if isinstance(src, mm.Filter) else mm.Filter(src)
     images = {"in": image} if image is not None else {}
     return CpuFilter(flt.ir_json_raw).render(w, h, uservals=uv, images=images, t=t, intersample=intersample)
 
@@ -42,7 +43,7 @@ GOLDEN = [
 
 @pytest.mark.parametrize("name,golden,uv,needs,tol", GOLDEN)
 def test_oracle_matches_reference_golden(name, golden, uv, needs, tol, marlene):
-    got = oracle_render(W.ALL[name], uv, marlene if needs else None)
+    got = oracle_render(F.load(name), uv, marlene if needs else None)
     want = load_png_rgb(golden)
     d = np.abs(got[:, :, :3].astype(int) - want.astype(int))
     assert d.max() <= tol
@@ -52,27 +53,6 @@ def test_oracle_matches_reference_golden(name, golden, uv, needs, tol, marlene):
 
 def test_ident_golden_equals_input(marlene):
     assert np.array_equal(load_png_rgb("utilities_ident.png"), marlene)
-
-
-@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present")
-@pytest.mark.parametrize("name,path,uv", [
-    ("mandelbrot", "examples/Render/Mandelbrot.mm", {}), ("ident", "examples/Utilities/Ident.mm", {}),
-    ("pond", "examples/Distorts/Pond.mm", {}), ("gaussian_blur", "examples/Blur/Gaussian Blur.mm", {"dev": 0.07}),
-    ("droste", "examples/Map/Droste.mm", {}), ("droste", "examples/Map/Droste.mm", {"NoTransparency": 1}),
-    ("droste", "examples/Map/Droste.mm", {"ShowGrid": 1, "ShowFrame": 1, "HyperDroste": 1, "Untwist": 1}),
-    ("droste", "examples/Map/Droste.mm", {"ShowBothPoles": 1, "AutoSetPeriodicity": 1, "MirrorEffect": 1, "Strands": 2}),
-    ("droste", "examples/Map/Droste.mm", {"TilePoles": 1, "FractalPoints": 3, "ExternalTransparency": 1,
-                                          "LevelFrequency": 2, "StartingLevel": 2}),
-    ("closure_value", "tests/Apply.mm", {}), ("closure_call", "tests/Circle.mm", {}),
-    ("closure_arg", "tests/Closure.mm", {}), ("nested_calls", "tests/Twice.mm", {}),
-])
-def test_workload_text_equals_reference_script(name, path, uv, marlene):
-    """Our statements of the benchmark filters compute exactly what the reference's scripts do."""
-    theirs = open(os.path.join(REFERENCE, path)).read()
-    for t in (0.0, 0.3):
-        a = oracle_render(W.ALL[name], uv, marlene, t=t)
-        b = oracle_render(theirs, uv, marlene, t=t)
-        assert np.array_equal(a, b)
 
 
 # ---- golden sweep over the reference's test-suite where the filters are supported --------
@@ -195,11 +175,10 @@ def test_passes_preserve_results_on_cpu(path, marlene):
 def test_userval_specialisation_preserves_results_on_cpu(name, uv):
     """specialize_constants (SCCP with the user values as literals + the reference's literal folds)
     against the generic IR as lowered, both printed by the oracle."""
-    src = W.ALL[name]
     w, h = 120, 80
-    img = W.synthetic_image(w, h, seed=6)
-    images = {"in": img} if "image in" in src else {}
-    generic = mm.Filter(src)
+    img = F.synthetic_image(w, h, seed=6)
+    generic = F.load(name)
+    images = {"in": img} if F.image_names(generic) else {}
     special = generic.specialized(uv)
     # -fno-builtin on both sides: with the user values as literals gcc would evaluate the frame-constant
     # libm calls itself (MPFR/MPC, correctly rounded) instead of calling glibc (see CpuFilter)
@@ -232,8 +211,8 @@ def test_tile_division_by_multiply_high_is_exact_where_it_is_used():
 def test_closure_render_takes_arguments_at_the_current_time_and_runs_its_body_at_t_zero():
     """render_image's closure branch (builtins.c:273-298) on the oracle: the closure's calc_lines runs on a frame with
     t = 0.0 and frame = 0, its arguments are what the main filter's code computed at the current t."""
-    TIMED_ARG = W.CLOSURE_TIMED_ARG
-    img = W.synthetic_image(96, 64, seed=3)
+    TIMED_ARG = F.CLOSURE_TIMED_ARG
+    img = F.synthetic_image(96, 64, seed=3)
     a = CpuFilter(mm.Filter(TIMED_ARG).ir_json_raw).render(96, 64, images={"in": img}, t=0.5, frame=7)
     fb = mm.Filter(TIMED_ARG.replace("k * (1 + t)", "k"))
     for t, frame in ((0.0, 0), (0.9, 3)):
@@ -247,14 +226,14 @@ def test_recursive_filter_calls_at_run_time_and_unrolls_with_literals():
     every depth.  With the user values baked in the recursion is unrolled while lowering instead; the two
     forms must agree byte for byte.  depth = 1 equals the plain fetch; a recursion that never ends is cut
     off at MM_MAX_CALL_DEPTH (zeros) in the oracle exactly as in the kernel."""
-    flt = mm.Filter(W.RECURSIVE)
+    flt = F.load("recursive")
     assert [u["name"] for u in flt.uservals] == ["in", "depth", "s"]
     raw = json.loads(flt.ir_json_raw)
     assert [fn["filter"] for fn in raw["functions"]] == ["tree"] and '"filtercall"' in flt.ir_json_raw
     assert "mm_filter_0<0>" in flt.kernel_source and "mm_filter_0<MM_D + 1>" in flt.kernel_source
-    img = W.synthetic_image(64, 48, seed=2)
+    img = F.synthetic_image(64, 48, seed=2)
     generic = CpuFilter(flt.ir_json_raw)
-    ident = CpuFilter(mm.Filter(W.IDENT).ir_json_raw).render(64, 48, images={"in": img})
+    ident = CpuFilter(F.load("ident").ir_json_raw).render(64, 48, images={"in": img})
     assert np.array_equal(generic.render(64, 48, uservals={"depth": 1}, images={"in": img}), ident)
     sizes = []
     for d in (1, 2, 4, 7):
@@ -295,7 +274,7 @@ def test_dynamic_subscripts_follow_tree_vector_semantics():
     clamped to the tuple, elements are floats, a write replaces one element.  Expected values
     computed independently with numpy."""
     w, h = 64, 8
-    out = CpuFilter(mm.Filter(W.TREE_VECTOR).ir_json_raw).render(w, h, floatmap=True)
+    out = CpuFilter(F.load("tree_vector").ir_json_raw).render(w, h, floatmap=True)
     col = np.arange(w, dtype=np.float64)
     x = ((col - (w - 1) / 2.0) / ((w - 1) / 2.0)).astype(np.float32)                        # X = 1
     for row in range(h):
@@ -343,7 +322,7 @@ def test_overload_resolution_and_types():
 def test_frame_constant_code_is_hoisted():
     """Droste's user-value-only set-up must land in the prologue slice, the per-pixel slice
     must still contain the complex log/exp chain."""
-    ir = mm.Filter(W.DROSTE).ir
+    ir = F.load("droste").ir
 
     def count(b, key, pred):
         n = 0
@@ -361,14 +340,14 @@ def test_frame_constant_code_is_hoisted():
 
 
 def test_all_workloads_compile_for_gfx950_offline():
-    for name, src in W.ALL.items():
-        f = mm.Filter(src)
+    for name in F.NAMES:
+        f = F.load(name)
         assert "mm_pixels(mm_args A" in f.kernel_source
         assert f.jit(load=False) > 1000, name
 
 
 def test_generated_c_of_oracle_has_reference_shape():
-    src = CpuFilter(mm.Filter(W.MANDELBROT).ir_json).source
+    src = CpuFilter(F.load("mandelbrot").ir_json).source
     assert "CALC_VIRTUAL_Y(row + A->region_y" in src and "while (" in src and "mmo_store_pixel" in src
 
 
@@ -701,11 +680,11 @@ def test_pair_mode_engages_for_arithmetic_filters(monkeypatch):
     from tests.fuzz_filters import make_filter_arith
     monkeypatch.delenv("MMHIP_PAIR", raising=False)
     marker = "mm_p += 2)"
-    flt = mm.Filter(W.MANDELBROT, specialize=True)
+    flt = F.load("mandelbrot", specialize=True)
     assert marker in flt.specialized({}).kernel_source and marker not in flt.kernel_source
     monkeypatch.setenv("MMHIP_PAIR", "1")
-    assert marker in mm.Filter(W.MANDELBROT).kernel_source
+    assert marker in F.load("mandelbrot").kernel_source
     assert sum(marker in mm.Filter(make_filter_arith(s)).kernel_source for s in range(40)) >= 35
-    assert marker not in mm.Filter(W.POND).kernel_source and marker not in mm.Filter(W.IDENT).kernel_source
+    assert marker not in F.load("pond").kernel_source and marker not in F.load("ident").kernel_source
     monkeypatch.setenv("MMHIP_PAIR", "0")
-    assert marker not in mm.Filter(W.MANDELBROT).kernel_source
+    assert marker not in F.load("mandelbrot").kernel_source

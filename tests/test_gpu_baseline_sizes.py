@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from mathmap_amd._lib import lib
 from oracle.ccgen import CpuFilter, gauss_rows
 from tests.expectations import Expectations
@@ -32,9 +32,9 @@ def test_droste_8192_bands_match_oracle(uv):
     """BASELINE config 2 (examples/Map/Droste on an 8192 x 8192 input): defaults -- one bilinear tap
     per pixel -- and NoTransparency=1, which drives the multi-tap level loop."""
     w = h = 8192
-    img = W.synthetic_image(w, h, seed=1)
+    img = F.synthetic_image(w, h, seed=1)
     for specialize in (True, False):
-        flt = mm.Filter(W.DROSTE, specialize=specialize)
+        flt = F.load("droste", specialize=specialize)
         inv = flt.invoke(w, h)
         for k, v in uv.items():
             inv.set(k, v)
@@ -58,9 +58,9 @@ def test_pond_8192_frames_match_oracle(k):
     """BASELINE config 4/5 (examples/Distorts/Pond, 120-frame 8192 x 8192 animation): frame k of 120,
     t = k / 120 computed like the CLI does ((float)frame / (float)num_frames, mathmap_cmdline.c:835)."""
     w = h = 8192
-    img = W.synthetic_image(w, h, seed=1)
+    img = F.synthetic_image(w, h, seed=1)
     t = float(np.float32(k) / np.float32(120))
-    flt = mm.Filter(W.POND, specialize=True)
+    flt = F.load("pond", specialize=True)
     inv = flt.invoke(w, h)
     inv.set_image("in", img)
     got = inv.render(t=t, frame=k)
@@ -87,7 +87,7 @@ def test_gauss_sigma20_16384_rows_are_bit_exact(size, sigma):
     (the blur's last kernel packs it, the pixel kernel is skipped) must be its exact pack.
     MM_TEST_GAUSS_SIZE overrides the size (development on smaller machines)."""
     w = h = int(os.environ.get("MM_TEST_GAUSS_SIZE", size))
-    img = W.synthetic_image(w, h, seed=4)
+    img = F.synthetic_image(w, h, seed=4)
     dev_uv = np.float32(sigma / ((w - 1) / 2.0))          # sigma_px = |dev * (W-1)/2| (gauss.c:659-660)
     uv = {"hdev": float(dev_uv), "vdev": float(dev_uv)}
     rows = sorted({0, 1, 2, 19, 454, 455, h // 2 - 1, h // 2, h - 456, h - 20, h - 2, h - 1} |
@@ -96,7 +96,7 @@ def test_gauss_sigma20_16384_rows_are_bit_exact(size, sigma):
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
     want = gauss_rows(img, dev_uv, dev_uv, rows, threads=threads)
 
-    flt = mm.Filter(W.GAUSS_DIRECT)
+    flt = F.load("gauss_direct")
     inv = flt.invoke(w, h)
     for k, v in uv.items():
         inv.set(k, v)

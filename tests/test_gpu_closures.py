@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter
 from tests.gpu_util import make_invocation, render_device, stats
 
@@ -57,7 +57,7 @@ end
                                           ("two", TWO_CLOSURES, 0)])
 def test_native_filter_on_closure_image(name, src, tol):
     w, h = 212, 131
-    img = W.synthetic_image(w, h, seed=3)
+    img = F.synthetic_image(w, h, seed=3)
     flt, inv = make_invocation(src, w, h, {}, {"in": img})
     cf = CpuFilter(flt.ir_json_raw)
     for k, t in ((0.7, 0.0), (1.3, 0.6), (1.3, 0.2), (0.4, 0.9)):
@@ -75,7 +75,7 @@ def test_native_filter_on_closure_image(name, src, tol):
     assert np.array_equal(full, banded)
 
 
-TIMED_ARG = W.CLOSURE_TIMED_ARG
+TIMED_ARG = F.CLOSURE_TIMED_ARG
 
 
 def test_closure_arguments_are_values_of_the_current_frame_and_its_body_runs_at_t_zero():
@@ -84,7 +84,7 @@ def test_closure_arguments_are_values_of_the_current_frame_and_its_body_runs_at_
     the main filter's code at the current time (backends/cc.c:158-188).  So k * (1 + t) at t = 0.5, k = 0.5 must give
     what the constant 0.75 gives at any t and frame -- and HIP = oracle."""
     w, h = 160, 96
-    img = W.synthetic_image(w, h, seed=3)
+    img = F.synthetic_image(w, h, seed=3)
     flt, inv = make_invocation(TIMED_ARG, w, h, {}, {"in": img})
     got = inv.render(t=0.5, frame=7)
     want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, t=0.5, frame=7)
@@ -104,7 +104,7 @@ def test_closure_images_for_native_filters_through_the_reference_abi(name):
     from mathmap_amd._lib import selftest_lib
     src = {"blur": BLUR_OF_CLOSURE, "render": RENDER_OF_CLOSURE, "two": TWO_CLOSURES, "timed_arg": TIMED_ARG}[name]
     w, h = 192, 128
-    img = np.ascontiguousarray(W.synthetic_image(w, h, seed=3))
+    img = np.ascontiguousarray(F.synthetic_image(w, h, seed=3))
     flt, inv = make_invocation(src, w, h, {}, {"in": img})
     want = inv.render(t=0.25)
     got = np.zeros((h, w, 4), np.uint8)
@@ -119,8 +119,8 @@ def test_native_filter_on_a_recursive_closure():
     phis of a top-level construct) and calls itself at run time: the closure's render kernel calls the main code's
     filter functions (generate_hip(..., functions_of)).  Generic kernel = oracle = kernel with the depth baked in."""
     w, h = 160, 96
-    img = W.synthetic_image(w, h, seed=3)
-    src = W.RECURSIVE + """
+    img = F.synthetic_image(w, h, seed=3)
+    src = F.RECURSIVE + """
 filter blurred_tree (image in, int depth: 1-16 (3), float dev: 0-1 (0.02))
   b = gaussian_blur(tree(in, depth, 0.7), dev, dev);
   b(xy)
@@ -139,7 +139,7 @@ end
 
 def test_convolve_on_closure_image():
     w, h = 96, 64
-    img = W.synthetic_image(w, h, seed=3)
+    img = F.synthetic_image(w, h, seed=3)
     yy, xx = np.mgrid[0:h, 0:w]
     blob = np.exp(-(((xx - w // 2) / 3.0) ** 2 + ((yy - (h // 2 - 1)) / 2.0) ** 2))
     kern = np.repeat((blob * 255).astype(np.uint8)[:, :, None], 3, axis=2)
@@ -153,7 +153,7 @@ def test_closure_render_survives_an_ir_round_trip():
     """The IR dump carries the closure's render code ("closure_renders"): a filter rebuilt from it
     (mmhip_compile_ir_json, what the reference-ABI tier and the fixtures use) renders the same frame."""
     w, h = 128, 80
-    img = W.synthetic_image(w, h, seed=5)
+    img = F.synthetic_image(w, h, seed=5)
     flt, inv = make_invocation(BLUR_OF_CLOSURE, w, h, {"k": 1.1}, {"in": img})
     a = inv.render(t=0.5)
     flt2 = mm.Filter("", ir_json=flt.ir_json_raw)

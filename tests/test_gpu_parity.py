@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter
 from tests.conftest import load_png_rgb
 from tests.expectations import Expectations
@@ -23,7 +23,8 @@ EXP_GOLDEN = Expectations("gpu_vs_golden")
 
 
 def hip_render(src, w, h, uservals=None, image=None, t=0.0, **opts):
-    flt = mm.Filter(src, **opts)
+    """`src`: .mm text, or the name of a filter of tests/filters.py (the reference's filters load from IR fixtures)."""
+    flt = F.load(src, **opts) if src in F.NAMES else mm.Filter(src, **opts)
     inv = flt.invoke(w, h)
     for k, v in (uservals or {}).items():
         inv.set(k, v)
@@ -59,7 +60,7 @@ GOLDEN_CASES = [
 @pytest.mark.parametrize("name,golden,uv,needs_image,tol", GOLDEN_CASES)
 def test_hip_matches_reference_golden(name, golden, uv, needs_image, tol, marlene):
     """256x256, -i: what tests/run_tests.sh of the reference renders."""
-    _, got = hip_render(W.ALL[name], 256, 256, uv, marlene if needs_image else None)
+    _, got = hip_render(name, 256, 256, uv, marlene if needs_image else None)
     want = load_png_rgb(golden)
     mx, nd, n1 = stats(got[:, :, :3], want)
     assert mx <= tol, "%s: max diff %d (%d values differ, %d by more than 1)" % (name, mx, nd, n1)
@@ -75,9 +76,9 @@ def test_hip_matches_reference_golden(name, golden, uv, needs_image, tol, marlen
 def test_hip_matches_oracle(name, uv, tol, size):
     """Ragged (non tile-multiple, non-square) sizes on a seeded synthetic image."""
     w, h = size
-    img = W.synthetic_image(w, h, seed=3)
-    needs = "image in" in W.ALL[name]
-    flt, got = hip_render(W.ALL[name], w, h, uv, img if needs else None, t=0.37)
+    img = F.synthetic_image(w, h, seed=3)
+    needs = bool(F.image_names(F.load(name)))
+    flt, got = hip_render(name, w, h, uv, img if needs else None, t=0.37)
     want = cpu_render(flt, w, h, uv, img if needs else None, t=0.37)
     mx, nd, n1 = stats(got, want)
     case = "oracle/%s/%s/%dx%d" % (name, ",".join("%s=%s" % kv for kv in sorted(uv.items())), w, h)
@@ -104,9 +105,9 @@ def test_gauss_iir_float_map_is_bit_exact(size, segments, monkeypatch):
     from mathmap_amd._lib import lib
     w, h = size[:2]
     sx, sy = size[2:] if len(size) > 2 else (2.0, 1.5)                  # sigma in pixels: IIR path
-    img = W.synthetic_image(w, h, seed=11)
+    img = F.synthetic_image(w, h, seed=11)
     uv = {"hdev": 2 * sx / max(w - 1, 1), "vdev": 2 * sy / max(h - 1, 1)}
-    flt = mm.Filter(W.GAUSS_DIRECT)
+    flt = F.load("gauss_direct")
     inv = flt.invoke(w, h)
     for k, v in uv.items():
         inv.set(k, v)
@@ -140,11 +141,11 @@ def test_gauss_direct_output_equals_pixel_kernel(size, sig, monkeypatch):
     import ctypes as C
     from mathmap_amd._lib import lib
     w, h = size
-    img = W.synthetic_image(w, h, seed=21)
+    img = F.synthetic_image(w, h, seed=21)
     uv = {"hdev": 2 * sig[0] / (w - 1), "vdev": 2 * sig[1] / (h - 1)}
 
     def make():
-        flt = mm.Filter(W.GAUSS_DIRECT)
+        flt = F.load("gauss_direct")
         inv = flt.invoke(w, h)
         for k, v in uv.items():
             inv.set(k, v)
@@ -220,9 +221,9 @@ def test_gauss_row_stripes_with_local_halo_equal_full_frame():
     import ctypes as C
     from mathmap_amd._lib import lib
     w, h = 640, 1500
-    img = W.synthetic_image(w, h, seed=13)
+    img = F.synthetic_image(w, h, seed=13)
     uv = {"hdev": 2 * 3.0 / (w - 1), "vdev": 2 * 2.5 / (h - 1)}       # sigma 3 px / 2.5 px -> halo 59 rows
-    flt = mm.Filter(W.GAUSS_DIRECT)
+    flt = F.load("gauss_direct")
 
     def render(stripes, margin):
         inv = flt.invoke(w, h)
@@ -254,7 +255,7 @@ def test_edge_behaviours_match_oracle(ex, ey, intersample):
     REFLECT, ROTATE in every mix of axes, sampling far outside the image, through the branch-free
     hot fetch and the early-exit one (odd image sizes so the C `%` cases differ): bit-exact."""
     w, h = 160, 96
-    img = W.synthetic_image(53, 37, seed=21)
+    img = F.synthetic_image(53, 37, seed=21)
     src = "filter e (image in) in(xy * 2.7 + xy:[0.31, -0.23]) end"
     colors = (0x20406080, 0xC0A01055)
     for extra in ("", " * in(xy * 0.9)" * 0):
@@ -287,7 +288,7 @@ def test_nan_and_huge_coordinates_follow_x86_conversion(intersample):
     the reference's byte is the low byte of a 64-bit conversion of ~1e32: the branch-free fetch
     flags such a pixel and the work-item redoes it in the generic loop (mm_x86_byte)."""
     w, h = 128, 64
-    img = W.synthetic_image(w, h, seed=8)
+    img = F.synthetic_image(w, h, seed=8)
     nan = "filter n (image in) q = exp(x * 1000 + 900) * 0; in(xy + xy:[q, 0]) end"
     wild = ("filter n (image in) q = exp(x * 1000 + 900); big = x * 1000000 * 1000000 * 1000000 * 1000000 * 1000000; "
             "k = floor(big) + floor(q * 0); in(xy + xy:[q, 0]) * 0.5 + in(xy:[big, y]) * 0.25 + in(xy * (1 + k * 0)) * 0.25 end")
@@ -309,12 +310,11 @@ def test_degenerate_frame_sizes(size):
     """One-pixel-wide / -high frames: (W-1)/2 = 0 makes the virtual coordinates inf or NaN in the
     reference too; every workload must still agree with the oracle."""
     w, h = size
-    img = np.ascontiguousarray(W.synthetic_image(max(w, 2), max(h, 2), seed=3)[:h, :w])
+    img = np.ascontiguousarray(F.synthetic_image(max(w, 2), max(h, 2), seed=3)[:h, :w])
     for name in ("mandelbrot", "ident", "pond", "droste", "gauss_direct"):
-        src = W.ALL[name]
-        needs = "image in" in src
         uv = {"hdev": 0.9, "vdev": 0.8} if name == "gauss_direct" else {}
-        flt = mm.Filter(src)
+        flt = F.load(name)
+        needs = bool(F.image_names(flt))
         inv = flt.invoke(w, h)
         for k, v in uv.items():
             inv.set(k, v)
@@ -327,8 +327,8 @@ def test_degenerate_frame_sizes(size):
 
 def test_nearest_sampling_matches_oracle():
     w, h = 300, 200
-    img = W.synthetic_image(w, h, seed=5)
-    flt, got = hip_render(W.POND, w, h, {}, img, t=0.1, intersample=False)
+    img = F.synthetic_image(w, h, seed=5)
+    flt, got = hip_render("pond", w, h, {}, img, t=0.1, intersample=False)
     want = cpu_render(flt, w, h, {}, img, t=0.1, intersample=False)
     assert stats(got, want)[0] <= 1
 
@@ -338,7 +338,7 @@ def test_row_bands_compose_to_full_frame():
     import ctypes as C
     from mathmap_amd._lib import lib
     w, h = 512, 384
-    flt = mm.Filter(W.MANDELBROT)
+    flt = F.load("mandelbrot")
     inv = flt.invoke(w, h)
     full = inv.render()
     dev = lib().mmhip_device_alloc(w * h * 4)
@@ -358,7 +358,7 @@ def test_mandelbrot_8192_stripe_property():
     """BASELINE size: the full 8192x8192 frame, checked against the oracle on sampled row
     bands (the oracle would need minutes for the whole frame)."""
     w = h = 8192
-    flt = mm.Filter(W.MANDELBROT)
+    flt = F.load("mandelbrot")
     inv = flt.invoke(w, h)
     got = inv.render()
     cf = CpuFilter(flt.ir_json_raw)
@@ -382,15 +382,15 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     import ctypes as C
     from mathmap_amd._lib import lib, selftest_lib
     w, h = 256, 256
-    src = W.ALL[name]
-    needs = "image in" in src
-    flt = mm.Filter(src)
+    flt = F.load(name)
+    src = F.SOURCES.get(name) or flt.ir_json_raw      # the self-test takes .mm text or an IR dump
+    needs = bool(F.image_names(flt))
     inv = flt.invoke(w, h)
     if needs:
         inv.set_image("in", marlene)
     if name == "curve_gradient":     # the self-test passes the same tables through curve_t / gradient_t
-        inv.set_curve("tone", W.test_curve())
-        inv.set_gradient("colors", W.test_gradient())
+        inv.set_curve("tone", F.test_curve())
+        inv.set_gradient("colors", F.test_gradient())
     want = inv.render(t=0.25)   # gaussian_blur: default dev = 0 -> sigma 0 -> FIR path with both passes skipped
     got = np.zeros((h, w, 4), np.uint8)
     img = np.ascontiguousarray(marlene)
@@ -410,9 +410,10 @@ def test_reference_abi_tier_specialises_from_the_second_frame(marlene):
     from mathmap_amd._lib import lib, selftest_lib
     w, h = 256, 256
     for name in ("mandelbrot", "pond"):
-        src = W.ALL[name]
-        needs = "image in" in src
-        inv = mm.Filter(src).invoke(w, h)
+        flt = F.load(name)
+        src = flt.ir_json_raw
+        needs = bool(F.image_names(flt))
+        inv = flt.invoke(w, h)
         if needs:
             inv.set_image("in", marlene)
         want = inv.render(t=0.5)
@@ -522,9 +523,9 @@ def test_gauss_fir_path_matches_oracle(hdev, vdev, flat):
         img[100:140, 50:300] = (200, 120, 30)
         img[:, 170:173] = 255
     else:
-        img = W.synthetic_image(w, h, seed=9)
+        img = F.synthetic_image(w, h, seed=9)
     uv = {"hdev": hdev, "vdev": vdev}
-    flt, got = hip_render(W.GAUSS_DIRECT, w, h, uv, img)
+    flt, got = hip_render("gauss_direct", w, h, uv, img)
     want = cpu_render(flt, w, h, uv, img)
     assert stats(got, want)[0] <= 1
 
@@ -535,8 +536,8 @@ def test_output_bpp_variants(bpp):
     import ctypes as C
     from mathmap_amd._lib import lib
     w, h = 200, 120
-    img = W.synthetic_image(w, h, seed=2)
-    flt = mm.Filter(W.POND)
+    img = F.synthetic_image(w, h, seed=2)
+    flt = F.load("pond")
     inv = flt.invoke(w, h)
     inv.set_image("in", img)
     dev = lib().mmhip_device_alloc(w * h * bpp)
@@ -558,8 +559,8 @@ def test_supersampling_matches_oracle(intersample):
     from mathmap_amd._lib import lib
     from oracle.ccgen import render_supersampled
     w, h = 211, 157
-    img = W.synthetic_image(w, h, seed=4)
-    flt = mm.Filter(W.POND, intersample=intersample, supersampling=True)
+    img = F.synthetic_image(w, h, seed=4)
+    flt = F.load("pond", intersample=intersample, supersampling=True)
     inv = flt.invoke(w, h)
     inv.set_image("in", img)
     dev = lib().mmhip_device_alloc(w * h * 4)
@@ -583,7 +584,7 @@ def test_command_line_reproduces_golden(tmp_path, marlene):
     import os
     cli = os.path.join(ROOT, "mathmap_amd", "mathmap_hip_cli")
     script = tmp_path / "pond.mm"
-    script.write_text(W.POND)
+    script.write_text(F.ir_text("pond"))      # the CLI takes an IR dump in place of .mm text
     out = tmp_path / "out.png"
     r = subprocess.run([cli, "-i", "-f", str(script), "-Din=" + os.path.join(GOLDEN, "marlene.png"), str(out)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -593,7 +594,7 @@ def test_command_line_reproduces_golden(tmp_path, marlene):
     assert np.abs(got.astype(int) - load_png_rgb("distorts_pond.png").astype(int)).max() <= 1
     # render test with -s and -D for a scalar user value
     script2 = tmp_path / "mandel.mm"
-    script2.write_text(W.MANDELBROT)
+    script2.write_text(F.ir_text("mandelbrot"))
     out2 = tmp_path / "m.png"
     r = subprocess.run([cli, "-i", "-s", "256x256", "-f", str(script2), str(out2)], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True)
@@ -610,12 +611,11 @@ def test_userval_specialisation_is_bit_identical(name, uv):
     """The specialising JIT (scalar user values baked in, reference-style literal folds,
     optimistic constant propagation through loop phis) must not change a single byte."""
     w, h = 400, 300
-    src = W.ALL[name]
-    img = W.synthetic_image(w, h, seed=6) if "image in" in src else None
-    _, generic = hip_render(src, w, h, uv, img, t=0.4)
-    _, special = hip_render(src, w, h, uv, img, t=0.4, specialize=True)
+    img = F.synthetic_image(w, h, seed=6) if F.image_names(F.load(name)) else None
+    _, generic = hip_render(name, w, h, uv, img, t=0.4)
+    _, special = hip_render(name, w, h, uv, img, t=0.4, specialize=True)
     assert np.array_equal(generic, special)
-    flt = mm.Filter(src, specialize=True)
+    flt = F.load(name, specialize=True)
     # changing a user value after the first render must re-specialise
     inv = flt.invoke(w, h)
     if img is not None:
@@ -632,17 +632,15 @@ def test_ir_origin_filters_specialise_too():
     re-lower; its variants are built from its own IR dump (bake_uservals + the same constant
     propagation) and must equal the generic kernel byte for byte."""
     w, h = 320, 200
-    img = W.synthetic_image(w, h, seed=4)
+    img = F.synthetic_image(w, h, seed=4)
     for name, uv in (("mandelbrot", {"num_iterations": 40, "pj": 0.2}), ("pond", {"height": 0.1}), ("droste", {})):
-        src = W.ALL[name]
-        ir = mm.Filter(src).ir_json_raw
         outs = []
         for spec in (False, True):
-            flt = mm.Filter("", ir_json=ir, specialize=spec)
+            flt = F.load(name, specialize=spec)
             inv = flt.invoke(w, h)
             for k, v in uv.items():
                 inv.set(k, v)
-            if "image in" in src:
+            if F.image_names(flt):
                 inv.set_image("in", img)
             outs.append(inv.render(t=0.2))
         assert np.array_equal(outs[0], outs[1]), name
@@ -650,8 +648,8 @@ def test_ir_origin_filters_specialise_too():
 
 def test_specialised_mandelbrot_8192_equals_generic():
     w = h = 8192
-    a = mm.Filter(W.MANDELBROT).invoke(w, h).render()
-    b = mm.Filter(W.MANDELBROT, specialize=True).invoke(w, h).render()
+    a = F.load("mandelbrot").invoke(w, h).render()
+    b = F.load("mandelbrot", specialize=True).invoke(w, h).render()
     assert np.array_equal(a, b)
 
 
@@ -739,7 +737,7 @@ def test_dynamic_subscripts_on_gpu():
     import ctypes as C
     from mathmap_amd._lib import lib
     w, h = 192, 96
-    flt = mm.Filter(W.TREE_VECTOR)
+    flt = F.load("tree_vector")
     for k in (0, 2, 3, 7):
         inv = flt.invoke(w, h)
         inv.set("k", k)
@@ -760,8 +758,8 @@ def test_curve_and_gradient_user_values(marlene):
     ramps and explicitly set tables, HIP vs oracle, bit-exact."""
     w = h = 128
     img = np.ascontiguousarray(marlene[:h, :w])
-    flt = mm.Filter(W.CURVE_GRADIENT)
-    for tables in ({}, {"tone": W.test_curve(), "colors": W.test_gradient()}):
+    flt = F.load("curve_gradient")
+    for tables in ({}, {"tone": F.test_curve(), "colors": F.test_gradient()}):
         inv = flt.invoke(w, h)
         inv.set_image("in", img)
         if tables:
@@ -770,11 +768,11 @@ def test_curve_and_gradient_user_values(marlene):
         got = inv.render()
         want = CpuFilter(flt.ir_json_raw).render(w, h, uservals=tables, images={"in": img})
         assert np.array_equal(got, want), stats(got, want)
-    assert not np.array_equal(got, mm.Filter(W.IDENT).invoke(w, h).render())
+    assert not np.array_equal(got, F.load("ident").invoke(w, h).render())
 
 
 def _fft_case(src, w, h, uv, images):
-    flt = mm.Filter(src)
+    flt = F.load(src) if src in F.NAMES else mm.Filter(src)
     inv = flt.invoke(w, h)
     for k, v in uv.items():
         inv.set(k, v)
@@ -791,24 +789,24 @@ def test_fft_native_filters_match_oracle(w, h):
     the oracle's direct long-double DFT, even and odd sizes, every flag combination.
     Tolerance: the reference itself uses FFTW, whose round-off differs from any other FFT's
     by O(1e-15) relative; after /n, the float store and the byte pack that is <= 1 LSB."""
-    img = W.synthetic_image(w, h, seed=3)
+    img = F.synthetic_image(w, h, seed=3)
     yy, xx = np.mgrid[0:h, 0:w]
     blob = np.exp(-(((xx - w // 2) / 3.0) ** 2 + ((yy - (h // 2 - 1)) / 2.0) ** 2))
     kern = np.repeat((blob * 255).astype(np.uint8)[:, :, None], 3, axis=2)
     kern[:, :, 1] = kern[:, :, 1] // 2
-    mask = W.synthetic_image(w, h, seed=9)
+    mask = F.synthetic_image(w, h, seed=9)
     for normalize in (0, 1):
         for copy_alpha in (0, 1):
-            got, want = _fft_case(W.CONVOLVE, w, h, {"normalize": normalize, "copy_alpha": copy_alpha},
+            got, want = _fft_case("convolve", w, h, {"normalize": normalize, "copy_alpha": copy_alpha},
                                   {"in": img, "kernel": kern})
             mx, nd, n1 = stats(got, want)
             assert mx <= 1, ("convolve", w, h, normalize, copy_alpha, mx, nd, n1)
     for copy_alpha in (0, 1):
-        got, want = _fft_case(W.HALF_CONVOLVE, w, h, {"copy_alpha": copy_alpha}, {"in": img, "mask": mask})
+        got, want = _fft_case("half_convolve", w, h, {"copy_alpha": copy_alpha}, {"in": img, "mask": mask})
         mx, nd, n1 = stats(got, want)
         assert mx <= 1, ("half_convolve", w, h, copy_alpha, mx, nd, n1)
     for ignore_alpha in (0, 1):
-        got, want = _fft_case(W.VISUALIZE_FFT, w, h, {"ignore_alpha": ignore_alpha}, {"in": img})
+        got, want = _fft_case("visualize_fft", w, h, {"ignore_alpha": ignore_alpha}, {"in": img})
         mx, nd, n1 = stats(got, want)
         assert mx <= 1, ("visualize_fft", w, h, ignore_alpha, mx, nd, n1)
 
@@ -818,16 +816,16 @@ def test_convolve_with_impulse_is_identity_at_2048():
     impulse at flat index n - nhalf (convolve.c:119-122) returns the input (<= 1 LSB), and
     the native-filter memo returns the same map on a second frame."""
     w = h = 2048
-    img = W.synthetic_image(w, h, seed=5)
+    img = F.synthetic_image(w, h, seed=5)
     kern = np.zeros((h, w, 3), np.uint8)
     kern[h // 2 - 1, w // 2] = 255
-    flt = mm.Filter(W.CONVOLVE)
+    flt = F.load("convolve")
     inv = flt.invoke(w, h)
     inv.set("normalize", 1)
     inv.set_image("in", img)
     inv.set_image("kernel", kern)
     got = inv.render()
-    ident = mm.Filter(W.IDENT).invoke(w, h)
+    ident = F.load("ident").invoke(w, h)
     ident.set_image("in", img)
     want = ident.render()
     mx, nd, n1 = stats(got, want)
@@ -840,8 +838,8 @@ def test_recursive_filter_calls_filter_functions_on_the_gpu():
     per render.  Bit-exact against the oracle's recursive C functions, and against the kernel with the
     depth baked in (recursion unrolled while lowering, no calls)."""
     w, h = 96, 64
-    img = W.synthetic_image(w, h, seed=2)
-    flt = mm.Filter(W.RECURSIVE)
+    img = F.synthetic_image(w, h, seed=2)
+    flt = F.load("recursive")
     assert "mm_filter_0<0>" in flt.kernel_source
     cpu = CpuFilter(flt.ir_json_raw)
     inv = flt.invoke(w, h)
@@ -915,8 +913,8 @@ def test_data_dependent_recursion_on_the_gpu():
     lowering-time unrolling could serve; mutual recursion between two filters; RAND inside the callee keeps the
     pixel's call counter.  Bit-exact against the oracle, including the cut-off at MM_MAX_CALL_DEPTH."""
     w, h = 128, 96
-    img = W.synthetic_image(w, h, seed=5)
-    cases = [(W.RECURSIVE_DATA, {}), (W.RECURSIVE_MUTUAL, {"n": 6}), (W.RECURSIVE_MUTUAL, {"n": 40})]
+    img = F.synthetic_image(w, h, seed=5)
+    cases = [(F.RECURSIVE_DATA, {}), (F.RECURSIVE_MUTUAL, {"n": 6}), (F.RECURSIVE_MUTUAL, {"n": 40})]
     for src, uv in cases:
         flt = mm.Filter(src)
         inv = flt.invoke(w, h)
@@ -939,7 +937,7 @@ def test_random_filters_hip_vs_oracle_and_specialised_vs_generic(seed):
     from tests.fuzz_filters import make_filter
     src, needs = make_filter(seed)
     w, h = 96, 64
-    img = W.synthetic_image(w, h, seed=1)
+    img = F.synthetic_image(w, h, seed=1)
     uv = {"k": 5, "m": 1.3}
     outs = []
     for spec in (False, True):
@@ -964,7 +962,7 @@ def test_random_filters_with_closures_complex_ops_and_options(seed):
     from tests.fuzz_filters import make_filter_ex
     src, names, opts = make_filter_ex(seed)
     w, h = 96, 64
-    imgs = {"in": W.synthetic_image(w, h, seed=1), "in2": W.synthetic_image(50, 70, seed=2)}
+    imgs = {"in": F.synthetic_image(w, h, seed=1), "in2": F.synthetic_image(50, 70, seed=2)}
     uv = {"k": seed % 7, "m": 0.3 + (seed % 5) * 0.4}
     outs = []
     for spec in (False, True):

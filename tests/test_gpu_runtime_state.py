@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter, render_supersampled
 from tests.gpu_util import make_invocation, render_device, stats
 
@@ -26,9 +26,9 @@ def test_render_size_change_reallocates_native_maps():
     blur's float map must follow the render size (it used to stay preview-sized: a device heap
     overflow) and the memo must not return the other size's map."""
     w, h = 320, 200
-    img = W.synthetic_image(w, h, seed=5)
+    img = F.synthetic_image(w, h, seed=5)
     uv = {"hdev": 0.03, "vdev": 0.02}
-    flt, inv = make_invocation(W.GAUSS_DIRECT, w, h, uv, {"in": img})
+    flt, inv = make_invocation(F.GAUSS_DIRECT, w, h, uv, {"in": img})
     cf = CpuFilter(flt.ir_json_raw)
     for rw, rh in ((80, 50), (w, h), (80, 50), (160, 100)):
         inv.set_render_size(rw, rh)
@@ -45,9 +45,9 @@ def test_supersampled_gaussian_blur(intersample):
     """-o on a filter with a native-filter call: the nested renders run gaussian_blur, which grows the
     native workspace -- the supersampling slices must not live in it."""
     w, h = 233, 141
-    img = W.synthetic_image(w, h, seed=6)
+    img = F.synthetic_image(w, h, seed=6)
     uv = {"hdev": 0.04, "vdev": 0.03}
-    flt, inv = make_invocation(W.GAUSS_DIRECT, w, h, uv, {"in": img}, intersample=intersample, supersampling=True)
+    flt, inv = make_invocation(F.GAUSS_DIRECT, w, h, uv, {"in": img}, intersample=intersample, supersampling=True)
     got = render_device(inv, w, h, supersampled=True)
     want = render_supersampled(CpuFilter(flt.ir_json_raw), w, h, uservals=uv, images={"in": img}, intersample=intersample)
     assert np.array_equal(got, want), stats(got, want)
@@ -61,7 +61,7 @@ def test_native_memo_follows_its_producer():
     c's own arguments did not change, but its input did (the reference keys the cache on image ids,
     cache.c:65-68), so c must be recomputed as well."""
     w, h = 200, 120
-    img = W.synthetic_image(w, h, seed=7)
+    img = F.synthetic_image(w, h, seed=7)
     flt, inv = make_invocation(CHAIN, w, h, {}, {"in": img})
     cf = CpuFilter(flt.ir_json_raw)
     for s in (0.02, 0.06, 0.06, 0.02):
@@ -74,8 +74,8 @@ def test_native_memo_follows_its_producer():
 def test_replacing_an_input_image_releases_the_old_upload():
     """set_image twice: the second upload replaces (and frees) the first; results follow the image."""
     w, h = 96, 64
-    a, b = W.synthetic_image(w, h, seed=1), W.synthetic_image(w, h, seed=2)
-    flt, inv = make_invocation(W.POND, w, h, {}, {"in": a})
+    a, b = F.synthetic_image(w, h, seed=1), F.synthetic_image(w, h, seed=2)
+    flt, inv = make_invocation("pond", w, h, {}, {"in": a})
     cf = CpuFilter(flt.ir_json_raw)
     first = inv.render(t=0.1)
     for k in range(20):
@@ -104,7 +104,7 @@ def test_native_filter_input_honours_edges_and_supersampling(ex, ey, supersampli
     invocation's supersampling flag (no +0.5), edge behaviours and edge colours.  A non-square input
     smaller than the canvas, so the blur's input map samples outside the image."""
     w, h = 160, 96
-    img = W.synthetic_image(53, 37, seed=21)
+    img = F.synthetic_image(53, 37, seed=21)
     colors = (0x20406080, 0xC0A01055)
     flt = mm.Filter(EDGE_BLUR, intersample=intersample, supersampling=supersampling, edge_x=ex, edge_y=ey)
     inv = flt.invoke(w, h)

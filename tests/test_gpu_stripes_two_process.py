@@ -21,7 +21,7 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %r)
     import numpy as np, torch, torch.distributed as dist
     import mathmap_amd as mm
-    from mathmap_amd import workloads as W
+    from tests import filters as F
     from mathmap_amd._lib import lib
     from mathmap_amd.striping import stripe_rows, gather_stripes, render_stripe, animation_frame_t
     dist.init_process_group("gloo")
@@ -41,14 +41,14 @@ WORKER = textwrap.dedent("""
             lib().mmhip_device_free(C.c_void_p(dev))
         return torch.from_numpy(out)
 
-    img = W.synthetic_image(w, h, seed=13)
+    img = F.synthetic_image(w, h, seed=13)
     res = {}
-    inv = mm.Filter(W.GAUSS_DIRECT).invoke(w, h)
+    inv = F.load("gauss_direct").invoke(w, h)
     inv.set("hdev", 2 * 3.0 / (w - 1)); inv.set("vdev", 2 * 2.5 / (h - 1))
     inv.set_image("in", img)
     blur = gather_stripes(stripe(inv, native_row_margin=0), h, rank, world)
     assert inv.direct_native_launches() == 1            # the stripe's pixels came straight out of the blur kernel
-    pond = mm.Filter(W.POND, specialize=True).invoke(w, h)
+    pond = F.load("pond", specialize=True).invoke(w, h)
     pond.set_image("in", img)
     frames = [gather_stripes(stripe(pond, t=animation_frame_t(k, 120), frame=k), h, rank, world) for k in (0, 37, 119)]
     if rank == 0:
@@ -60,7 +60,7 @@ WORKER = textwrap.dedent("""
 
 def test_two_process_gpu_stripes_equal_full_frame(tmp_path):
     import mathmap_amd as mm
-    from mathmap_amd import workloads as W
+    from tests import filters as F
     from mathmap_amd.striping import animation_frame_t
     from oracle.ccgen import CpuFilter
     script = tmp_path / "worker.py"
@@ -73,9 +73,9 @@ def test_two_process_gpu_stripes_equal_full_frame(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     got = np.load(out)
     w, h = 640, 451
-    img = W.synthetic_image(w, h, seed=13)
+    img = F.synthetic_image(w, h, seed=13)
     uv = {"hdev": 2 * 3.0 / (w - 1), "vdev": 2 * 2.5 / (h - 1)}
-    flt = mm.Filter(W.GAUSS_DIRECT)
+    flt = F.load("gauss_direct")
     inv = flt.invoke(w, h)
     for k, v in uv.items():
         inv.set(k, v)
@@ -83,7 +83,7 @@ def test_two_process_gpu_stripes_equal_full_frame(tmp_path):
     full = inv.render()
     assert np.array_equal(got["blur"], full)
     assert np.array_equal(full, CpuFilter(flt.ir_json_raw).render(w, h, uservals=uv, images={"in": img}))
-    pflt = mm.Filter(W.POND, specialize=True)
+    pflt = F.load("pond", specialize=True)
     pinv = pflt.invoke(w, h)
     pinv.set_image("in", img)
     cf = CpuFilter(pflt.ir_json_raw)

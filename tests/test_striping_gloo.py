@@ -15,13 +15,13 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %r)
     import numpy as np, torch, torch.distributed as dist
     import mathmap_amd as mm
-    from mathmap_amd import workloads as W
+    from tests import filters as F
     from mathmap_amd.striping import stripe_rows, gather_stripes, replicate_input
     from oracle.ccgen import CpuFilter
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     w, h = 96, 67                      # odd height: stripes differ by one row
-    cf = CpuFilter(mm.Filter(W.MANDELBROT).ir_json_raw)
+    cf = CpuFilter(F.load("mandelbrot").ir_json_raw)
     lo, hi = stripe_rows(h, rank, world)
     full = cf.render(w, h, rows=(lo, hi))          # only rows [lo,hi) are filled
     stripe = torch.from_numpy(np.ascontiguousarray(full[lo:hi]))
@@ -34,8 +34,8 @@ WORKER = textwrap.dedent("""
     from mathmap_amd.striping import animation_frame_t
     from oracle.ccgen import gauss_rows
     pw, ph = 120, 77
-    img = W.synthetic_image(pw, ph, seed=2)
-    pond = CpuFilter(mm.Filter(W.POND).ir_json_raw)
+    img = F.synthetic_image(pw, ph, seed=2)
+    pond = CpuFilter(F.load("pond").ir_json_raw)
     lo, hi = stripe_rows(ph, rank, world)
     frames = []
     for k in (0, 37, 119):
@@ -69,22 +69,22 @@ def test_two_rank_stripes_reassemble(tmp_path):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:]
     import mathmap_amd as mm
-    from mathmap_amd import workloads as W
+    from tests import filters as F
     from oracle.ccgen import CpuFilter
-    want = CpuFilter(mm.Filter(W.MANDELBROT).ir_json_raw).render(96, 67)
+    want = CpuFilter(F.load("mandelbrot").ir_json_raw).render(96, 67)
     assert np.array_equal(np.load(out), want)
     # the striped animation frames and the striped blur equal single full-frame renders
     from mathmap_amd.striping import animation_frame_t
     anim = np.load(str(out) + ".anim.npz")
     pw, ph = 120, 77
-    img = W.synthetic_image(pw, ph, seed=2)
-    pond = CpuFilter(mm.Filter(W.POND).ir_json_raw)
+    img = F.synthetic_image(pw, ph, seed=2)
+    pond = CpuFilter(F.load("pond").ir_json_raw)
     for k in (0, 37, 119):
         t = animation_frame_t(k, 120)
         assert t == float(np.float32(k) / np.float32(120))
         assert np.array_equal(anim["f%d" % k], pond.render(pw, ph, images={"in": img}, t=t, frame=k)), k
     assert not np.array_equal(anim["f37"], anim["f119"])
     dev = float(np.float32(2 * 3.0 / (pw - 1)))
-    gd = mm.Filter(W.GAUSS_DIRECT)
+    gd = F.load("gauss_direct")
     full = CpuFilter(gd.ir_json_raw).render(pw, ph, uservals={"hdev": dev, "vdev": dev}, images={"in": img})
     assert np.array_equal(anim["blur"], full)

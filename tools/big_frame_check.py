@@ -9,19 +9,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter
 
 
 def main():
     # --- Mandelbrot 40000 x 40000 (6.4 GB of RGBA8)
     w = h = 40000
-    flt = mm.Filter(W.MANDELBROT, specialize=True)
+    flt = F.load("mandelbrot", specialize=True)
     inv = flt.invoke(w, h)
     out = torch.empty((h, w), dtype=torch.int32, device="cuda")
     inv.render_rows(out.data_ptr(), 0, h)
     inv.sync()
-    cf = CpuFilter(mm.Filter(W.MANDELBROT).ir_json_raw)
+    cf = CpuFilter(F.load("mandelbrot").ir_json_raw)
     for lo in (0, 13333, 26844, 39992):
         want = cf.render(w, h, rows=(lo, lo + 8))[lo:lo + 8]
         got = out[lo:lo + 8].cpu().numpy().view(np.uint8).reshape(8, w, 4)
@@ -35,7 +35,7 @@ def main():
     band = rng.integers(0, 256, (64, w, 3), dtype=np.uint8)
     img = np.tile(band, (h // 64, 1, 1))
     img[:, :, 0] ^= (np.arange(h, dtype=np.uint32)[:, None] & 255).astype(np.uint8)     # rows differ
-    flt = mm.Filter(W.IDENT)
+    flt = F.load("ident")
     inv = flt.invoke(w, h)
     inv.set_image("in", img)
     out = torch.empty((h, w), dtype=torch.int32, device="cuda")

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter
 from tests.fuzz_filters import make_filter, make_filter_ex
 
@@ -20,7 +20,7 @@ def main():
     lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 400)
     w, h = 203, 131
     colors = (0x20406080, 0xC0A01055)
-    imgs = {"in": W.synthetic_image(150, 97, seed=1), "in2": W.synthetic_image(50, 70, seed=2)}
+    imgs = {"in": F.synthetic_image(150, 97, seed=1), "in2": F.synthetic_image(50, 70, seed=2)}
     inexact, errors, kernels, fetched, exact = [], [], 0, 0, 0
     for seed in range(lo, hi):
         for kind in ("plain", "ex"):

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter
 from fuzz_filters import make_filter, make_filter_ex
 
@@ -17,7 +17,7 @@ from fuzz_filters import make_filter, make_filter_ex
 def main():
     lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (400, 1000)
     w, h = 96, 64
-    imgs = {"in": W.synthetic_image(w, h, seed=1), "in2": W.synthetic_image(50, 70, seed=2)}
+    imgs = {"in": F.synthetic_image(w, h, seed=1), "in2": F.synthetic_image(50, 70, seed=2)}
     bad = []
     for seed in range(lo, hi):
         for variant in ("plain", "ex"):

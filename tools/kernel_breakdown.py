@@ -8,16 +8,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 
 CASES = [
     ("const colour (store+pack)", "filter c () rgba:[0.2,0.4,0.6,1] end", {}, False),
     ("grayColor(x) (coords+pack)", "filter c () grayColor(x) end", {}, False),
     ("rgba:[x,y,x*y,1]", "filter c () rgba:[x,y,x*y,1] end", {}, False),
-    ("ident nearest", W.IDENT, dict(intersample=False), True),
-    ("ident bilinear", W.IDENT, {}, True),
+    ("ident nearest", "ident", dict(intersample=False), True),
+    ("ident bilinear", "ident", {}, True),
     ("ident bilinear, half-pixel shift", "filter s (image in) in(xy + xy:[0.37/X/1000, 0.21/Y/1000]) end", {}, True),
-    ("pond", W.POND, {}, True),
+    ("pond", "pond", {}, True),
 ]
 
 
@@ -27,7 +27,8 @@ def main():
     img = torch.randint(0, 2 ** 31 - 1, (size, size), dtype=torch.int32, device=dev)
     out = torch.empty((size, size), dtype=torch.int32, device=dev)
     for name, src, opts, needs in CASES:
-        flt = mm.Filter(src, tile_w=int(os.environ.get('TILE_W', '0')), **opts)
+        tw = int(os.environ.get('TILE_W', '0'))
+        flt = F.load(src, tile_w=tw, **opts) if src in F.NAMES else mm.Filter(src, tile_w=tw, **opts)
         inv = flt.invoke(size, size)
         if needs:
             inv.set_image_device("in", img.data_ptr(), size, size)

@@ -2,10 +2,10 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter
 w, h = 128, 64
-img = W.synthetic_image(w, h, seed=8)
+img = F.synthetic_image(w, h, seed=8)
 colors = (0x30507090, 0xA0B0C0D0)
 srcs = {
  "nan": "filter n (image in) q = exp(x * 1000 + 900) * 0; in(xy + xy:[q, 0]) end",

@@ -2,17 +2,16 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 from oracle.ccgen import CpuFilter
 bad = []
 for (w, h) in [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (17, 2), (255, 3)]:
-    img = W.synthetic_image(max(w, 2), max(h, 2), seed=3)[:h, :w]
+    img = F.synthetic_image(max(w, 2), max(h, 2), seed=3)[:h, :w]
     for name in ("mandelbrot", "ident", "pond", "droste", "gauss_direct"):
-        src = W.ALL[name]
-        needs = "image in" in src
         uv = {"hdev": 0.9, "vdev": 0.8} if name == "gauss_direct" else {}
         try:
-            flt = mm.Filter(src)
+            flt = F.load(name)
+            needs = bool(F.image_names(flt))
             inv = flt.invoke(w, h)
             for k, v in uv.items(): inv.set(k, v)
             if needs: inv.set_image("in", np.ascontiguousarray(img))

@@ -9,13 +9,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mathmap_amd as mm
-from mathmap_amd import workloads as W
+from tests import filters as F
 
 
 def main():
     size = 8192
     out = torch.empty((size, size), dtype=torch.int32, device="cuda")
-    img = W.synthetic_image(size, size)
+    img = F.synthetic_image(size, size)
     for k in ("3", "1.2", "1"):
         flt = mm.Filter("filter z (image in) in(xy * %s) end" % k)
         inv = flt.invoke(size, size)
