@@ -410,13 +410,12 @@ def sub_record(torch, mm, F, name, size, uv, args, stream, cores, frames, warmup
     if host_img is None and d.needs_image:
         host_img = d.host_images()
     vs = []
-    for fr in sorted(set((verify_frames or []) + [first_frame + frames - 1])):
-        if fr != first_frame + frames - 1:
+    last = first_frame + frames - 1          # what d.out holds after the timed frames
+    for fr in [last] + sorted(set(verify_frames or []) - {last}):
+        if fr != last:
             d.render(fr, stream)
             torch.cuda.synchronize()
         vs.append(d.verify(fr, images=host_img))
-    d.render(first_frame + frames - 1, stream)
-    torch.cuda.synchronize()
     ent["verified"] = all(v["ok"] for v in vs)
     ent["verification"] = vs if len(vs) > 1 else vs[0]
     if not args.no_cpu_baseline:

@@ -1065,6 +1065,19 @@ struct Generator {
             int nt = fetches > 0;
             if (const char *e = getenv("MMHIP_NT_STORE")) nt = atoi(e);
             out << "#define MM_NT_STORE " << nt << "\n";
+            // Workgroup -> tile order.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Giving every
+            // XCD one contiguous band of tiles (1) lets neighbouring gathers share an L2 -- and makes every XCD's share of
+            // the work depend on *where* in the frame the work is: the rows of a Mandelbrot frame that cross the set iterate
+            // 2-3 times longer than its top and bottom rows, Droste's level loop runs for some regions only, and the XCDs
+            // that own the cheap bands idle while the others finish (first seen as two processes sharing the GPU rendering
+            // 20 % more frames than one: the idle XCDs took the other process's workgroups).  Tiles in dispatch order (0)
+            // spread every region over all XCDs.  A/B at 8192^2 (tools/ab_xcd_order.sh, profiles/r03_ab_xcd_order.txt):
+            // Mandelbrot 0.265 -> 0.210 ms, Droste 1.226 -> 0.864 (NoTransparency=1: 0.909 -> 0.853), Pond 0.552 = 0.552,
+            // Ident 0.134 -> 0.139: only a body that is little more than its fetch (uniform work, the streaming shape of
+            // auto_tile_w) keeps the bands.
+            int xo = fetches >= 1 && stmts <= 12;
+            if (const char *e = getenv("MMHIP_XCD_ORDER")) xo = atoi(e);
+            out << "#define MM_XCD_ORDER " << xo << "\n";
         }
         if (const char *e = getenv("MMHIP_PAIR_MASKS")) out << "#define MM_PAIR_MASKS " << atoi(e) << "\n";
         if (getenv("MMHIP_NO_SAME_TAPS")) out << "#define MM_NO_SAME_TAPS 1\n";      // A/B switches
@@ -1152,14 +1165,20 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         if (const char *e = getenv("MMHIP_WAVES_PER_EU")) out << "__attribute__((amdgpu_waves_per_eu(" << atoi(e) << "))) ";
         out << R"(extern "C" __global__ void __launch_bounds__(256) mm_pixels(mm_args A, const char *__restrict__ XY) {
   MM_INTERNALS
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs; give each
-  // XCD one contiguous band of tiles so neighbouring gathers share its L2.
+  // XCD-aware tile order (MM_XCD_ORDER, above): workgroups are dealt round-robin to the 8 XCDs; give each
+  // XCD one contiguous band of tiles so neighbouring gathers share its L2 -- or, for a kernel that reads nothing,
+  // take the tiles in dispatch order so that cheap and expensive regions of the frame are spread over all XCDs.
   const int tiles_x = (A.region_width + MM_TILE_W - 1) / MM_TILE_W;
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
+#if MM_XCD_ORDER
   const int xcd = bid & 7, q = bid >> 3;
   const int per = nwg >> 3, rem = nwg & 7;
   const int swz = xcd * per + (xcd < rem ? xcd : rem) + q;
+#else
+  const int swz = bid;
+  (void)nwg;
+#endif
   const int tile_y = A.tiles_magic ? (int)__umulhi((unsigned)swz, A.tiles_magic) : swz / tiles_x, tile_x = swz - tile_y * tiles_x;
   const int col = tile_x * MM_TILE_W + (threadIdx.x % MM_TILE_W);
   // a workgroup owns MM_TILE_W x (MM_TILE_H * A.ppt) pixels; each work-item walks A.ppt rows

@@ -42,8 +42,9 @@ def test_two_ranks_launch_themselves_and_report_one_line(mode, single):
     assert two["verified"] is True and two["verification"]["ranks_verified"] == 2
     assert two["host_delivered"]["n_gpus"] == 2 and two["host_delivered"]["host_copy_equals_device_frame"] is True
     assert single["verified"] is True
-    # two ranks time-share one GPU here: the whole-job rate must stay that of one rank on it
-    assert abs(two["value"] / single["value"] - 1.0) <= 0.10, (two["value"], single["value"])
+    # two ranks time-share one GPU here: the whole-job rate stays about that of one rank on it (two processes' kernels
+    # overlap at each other's tails, so somewhat more is possible; much less would mean ranks waiting on each other)
+    assert 0.90 <= two["value"] / single["value"] <= 1.35, (two["value"], single["value"])
     if mode == "stripes":      # a stripe is half the frame
         assert two["per_rank_kernel_ms"][0] < 0.75 * single["per_rank_kernel_ms"][0]
 
