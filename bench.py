@@ -520,11 +520,11 @@ def main():
         step(i)
     torch.cuda.synchronize()
     settle_ms, settle_frames = settle_clocks(torch, step, args.settle_ms)
+    wl.inv.drain_kernel_ms()                     # forget the warm-up launches' event pairs
+    wl.inv.drain_native_kernel_ms()
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    wl.inv.drain_kernel_ms()                     # forget the warm-up launches
-    wl.inv.drain_native_kernel_ms()
     for i in range(args.steps):
         step(i)                                  # queued back to back: no synchronisation per step
     torch.cuda.synchronize()

@@ -45,8 +45,6 @@ def test_two_ranks_launch_themselves_and_report_one_line(mode, single):
     # two ranks time-share one GPU here: the whole-job rate stays about that of one rank on it (two processes' kernels
     # overlap at each other's tails, so somewhat more is possible; much less would mean ranks waiting on each other)
     assert 0.90 <= two["value"] / single["value"] <= 1.35, (two["value"], single["value"])
-    if mode == "stripes":      # a stripe is half the frame
-        assert two["per_rank_kernel_ms"][0] < 0.75 * single["per_rank_kernel_ms"][0]
 
 
 def test_rank_count_mismatch_is_an_error():
