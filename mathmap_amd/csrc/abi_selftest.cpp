@@ -353,7 +353,9 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
                 if (st->kind == Stmt::Assign && st->rhs.kind == Rhs::Closure && st->rhs.filter->kind == Filter::MathMap &&
                     st->rhs.filter != m.main && std::find(have.begin(), have.end(), st->rhs.filter) == have.end()) {
                     have.push_back(st->rhs.filter);
-                    if (from_ir) throw CompileError("self-test: a closure of filter `" + st->rhs.filter->name + "' needs the filter's source");
+                    // an IR dump carries no bodies of the filters whose closures it applies inline: no code to hand over (the
+                    // backend asks for one only when the closure image reaches a native filter, and reports that itself)
+                    if (from_ir) continue;
                     closure_codes.push_back(lower_function(m, const_cast<Filter *>(st->rhs.filter)));
                     fn_codes.emplace_back();
                     fn_codes.back().filter = ex.filter(st->rhs.filter);
