@@ -313,12 +313,10 @@ struct IirState { double s1, s2, s3, s4, v1, v2, v3, v4; };
 // 512).  FAST: every block of the group and every block prefetched by it is a full interior block of
 // the segment -- straight-line code without a branch, which is also what lets the compiler count
 // the outstanding loads exactly instead of waiting for all of them at a join.
-// CK: steps between checkpoints (a multiple of IIR_U that divides the group length; k0 and s0 are multiples of it).
-template <bool FAST, int CK, class Src>
+template <bool FAST, class Src>
 __device__ __forceinline__ void causal_group(const Src &src, typename Src::raw_t (&ring)[IIR_PF + 1][IIR_U], IirState &st,
                                              double *__restrict__ ck, unsigned stride, unsigned lane, int kb0, int k0, int s0,
                                              int s1, float initial, const IirCoef &c) {
-    static_assert(CK % IIR_U == 0 && ((IIR_PF + 1) * IIR_U) % CK == 0, "checkpoint interval");
     double s1_ = st.s1, s2 = st.s2, s3 = st.s3, s4 = st.s4, v1 = st.v1, v2 = st.v2, v3 = st.v3, v4 = st.v4;
 #pragma unroll
     for (int j = 0; j <= IIR_PF; ++j) {
@@ -334,8 +332,8 @@ __device__ __forceinline__ void causal_group(const Src &src, typename Src::raw_t
 #pragma unroll
                 for (int u = 0; u < IIR_U; ++u) far[u] = src.fetch(kf + u < s1 ? kf + u : k0);   // past the end: unused
             }
-            if ((j * IIR_U) % CK == 0 && (FAST || (kb > 0 && kb >= s0))) {      // kb0 - k0 is a multiple of the group length
-                double *q = ck + (size_t)(kb / CK) * 4 * stride;
+            if (FAST || (kb > 0 && kb >= s0)) {
+                double *q = ck + (size_t)(kb / IIR_U) * 4 * stride;
                 // (read back by the anticausal kernel after this whole sweep: non-temporal, like the map)
                 __builtin_nontemporal_store(v1, &q[lane]);
                 __builtin_nontemporal_store(v2, &q[stride + lane]);
@@ -369,7 +367,7 @@ __device__ __forceinline__ void causal_group(const Src &src, typename Src::raw_t
     st = IirState{s1_, s2, s3, s4, v1, v2, v3, v4};
 }
 
-template <int CK, class Src>
+template <class Src>
 __device__ __forceinline__ void causal_sweep(const Src &src, double *__restrict__ ck, unsigned stride, unsigned lane, int k0,
                                              int s0, int s1, const IirCoef &c) {
     const float initial = src.decode(src.fetch(k0));
@@ -385,11 +383,11 @@ __device__ __forceinline__ void causal_sweep(const Src &src, double *__restrict_
     const int G = (IIR_PF + 1) * IIR_U;
     int kb0 = k0;
     do {        // the group with the edge steps, and a segment's warm-up groups (no checkpoints)
-        causal_group<false, CK>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
+        causal_group<false>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
         kb0 += G;
     } while (kb0 < s0 && kb0 < s1);
-    for (; kb0 + (2 * IIR_PF + 1) * IIR_U <= s1; kb0 += G) causal_group<true, CK>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
-    for (; kb0 < s1; kb0 += G) causal_group<false, CK>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
+    for (; kb0 + (2 * IIR_PF + 1) * IIR_U <= s1; kb0 += G) causal_group<true>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
+    for (; kb0 < s1; kb0 += G) causal_group<false>(src, ring, st, ck, stride, lane, kb0, k0, s0, s1, initial, c);
 }
 
 // One block of the causal recurrence re-run from its checkpoint (block 0: from the edge).
@@ -604,14 +602,14 @@ __device__ __forceinline__ void anticausal_sweep(const Src &src, const double *_
 // are exp(-1.783/sigma) and exp(-1.723/sigma) (gauss.c:57-58), so after halo = 22.7 sigma steps the
 // influence of the different start has decayed by e^-39 ~ 1e-17 before the first value that is
 // kept.  The true ends of a line keep the reference's start-up.
-template <int CK, class Src>
+template <class Src>
 __global__ void __launch_bounds__(256) k_iir_causal(Src in, double *__restrict__ ckpt, LineArgs g, IirCoef c) {
     const unsigned sgi = blockIdx.x / g.lane_blocks, lb = blockIdx.x % g.lane_blocks;
     const long L = (long)lb * 256 + threadIdx.x;
     const long stride = (long)g.lines * 4;
     if (L >= stride) return;
     const int s0 = (int)sgi * g.seg, s1 = min(g.n, s0 + g.seg), k0 = max(0, s0 - g.halo);
-    causal_sweep<CK>(in.for_lane(L), ckpt, (unsigned)stride, (unsigned)L, k0, s0, s1, c);
+    causal_sweep(in.for_lane(L), ckpt, (unsigned)stride, (unsigned)L, k0, s0, s1, c);
 }
 
 template <class Src>
@@ -630,257 +628,6 @@ __global__ void __launch_bounds__(256) k_iir_anticausal_T(Src in, const double *
     anticausal_sweep(in.for_lane(Lc), ckpt, (unsigned)stride, (unsigned)Lc, g.n, s0, s1, k1, c, tile[wave], lane, line0, g.lines, outT, po, active);
 }
 
-// ---- the anticausal kernel as a producer wave and a consumer wave per 64 lanes ---------------------------
-// k_iir_anticausal_T above runs two dependency chains per lane in one wave per SIMD -- all a 16384-line frame offers when
-// a lane owns both chains -- at ~350 registers.  With a lone wave on a SIMD every instruction, scalar and memory
-// instructions and every wait included, takes an issue slot from the f64 pipe: measured 62-76 % of the wave's cycles issue
-// vector instructions, 14-19 % are waits.  Here the two chains of a lane live in two waves of one workgroup:
-//   * the producer re-runs the causal recurrence of a super-block (CK steps, from its checkpoint, in the reference's
-//     order: the same values the causal sweep had) and leaves the CK causal values per lane in LDS;
-//   * the consumer takes the anticausal steps of the super-block before (the sweep runs towards step 0), adds the causal
-//     value from LDS, rounds to float (transfer_pixels, gauss.c:117-124) and writes 16 x 16 tiles transposed as before.
-// Two buffers in LDS, one workgroup barrier per super-block: the producer fills buffer B & 1 while the consumer reads the
-// other one.  Each wave has one chain and < 256 registers, so a SIMD holds two waves and one's waits, scalar bookkeeping
-// and memory instructions disappear behind the other's arithmetic.  CK = 32 halves the checkpoints (8 -> 4 bytes per pixel
-// and sweep, written and read) at 32 KB of LDS per workgroup -- four workgroups per CU, the eight waves it needs.
-__device__ __forceinline__ void pc_barrier() {
-    // LDS stores of this wave have landed before the partner is released; pending global loads stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int CK, class Src>
-__device__ __forceinline__ void pc_produce(const Src &src, const double *__restrict__ ck, unsigned stride, unsigned clane, int n,
-                                           int sg0, int sg1, const IirCoef &c, double (*vcbuf)[CK][64], int lane) {
-    typedef typename Src::raw_t raw_t;
-    struct Slot { raw_t s[CK]; raw_t r4[4]; double ck[4]; };
-    constexpr int R = CK <= 16 ? 3 : 2;          // ring of slots: a super-block's loads are issued R-1 super-blocks ahead
-    Slot slot[R];
-    const float initial_p = src.decode(src.fetch(0));
-    const int first = sg0 / CK, last = (sg1 + CK - 1) / CK - 1;          // this segment's super-blocks
-    auto load = [&](auto fast, int B, Slot &o) {
-        const int kb = B * CK;
-        if (decltype(fast)::value || (B > 0 && kb + CK <= n)) {
-            const raw_t *r = src.row(kb - 4);
-            const double *q = ck + (size_t)B * 4 * stride;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o.r4[i] = src.at(r, i);
-                o.ck[i] = *(const double *)((const char *)q + (((unsigned)i * stride + clane) << 3));
-            }
-#pragma unroll
-            for (int u = 0; u < CK; ++u) o.s[u] = src.at(r, 4 + u);
-        } else {
-#pragma unroll
-            for (int u = 0; u < CK; ++u) o.s[u] = src.fetch(kb + u < n ? kb + u : 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o.r4[i] = src.fetch(B > 0 ? kb - 4 + i : 0);
-                o.ck[i] = B > 0 ? ck[((size_t)B * 4 + i) * stride + clane] : 0.0;
-            }
-        }
-    };
-    // the causal steps of super-block B from its checkpoint (B = 0: from the line's edge), values to LDS
-    auto rerun = [&](auto interior, int B, const Slot &in, double (*out)[64]) {
-        const int kb = B * CK;
-        double cs1 = src.decode(in.r4[3]), cs2 = src.decode(in.r4[2]), cs3 = src.decode(in.r4[1]), cs4 = src.decode(in.r4[0]);
-        double cv1 = in.ck[0], cv2 = in.ck[1], cv3 = in.ck[2], cv4 = in.ck[3];
-#pragma unroll
-        for (int u = 0; u < CK; ++u) {
-            if (decltype(interior)::value) {
-                const double s0 = (double)src.decode(in.s[u]);
-                const double acc = iir_step_causal<Src::not_neg_zero>(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
-                out[u][lane] = acc;
-                cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
-                cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
-            } else {
-                double acc = 0.0;
-                if (kb + u < n) {
-                    const double s0 = (double)src.decode(in.s[u]);
-                    acc = (B == 0 && u < 4) ? iir_edge_step(u, s0, cs1, cs2, cs3, cv1, cv2, cv3, c.n_p, c.d_p, c.bd_p, initial_p)
-                                            : iir_step(s0, cs1, cs2, cs3, cs4, cv1, cv2, cv3, cv4, c.n_p, c.d_p);
-                    cs4 = cs3; cs3 = cs2; cs2 = cs1; cs1 = s0;
-                    cv4 = cv3; cv3 = cv2; cv2 = cv1; cv1 = acc;
-                }
-                out[u][lane] = acc;
-            }
-        }
-    };
-    // One step: loads of super-block B-(R-1) (slot far), causal values of B (slot cur) into buffer B & 1, barrier.
-    // FAST: B-(R-1) and B are full super-blocks with a checkpoint.
-    auto step = [&](auto fast, int B, Slot &cur, Slot &far) {
-        constexpr bool FAST = decltype(fast)::value;
-        if (FAST || B - (R - 1) >= first) load(fast, B - (R - 1), far);
-        if (FAST || (B > 0 && (B + 1) * CK <= n)) rerun(std::true_type{}, B, cur, vcbuf[B & 1]);
-        else rerun(std::false_type{}, B, cur, vcbuf[B & 1]);
-        pc_barrier();
-    };
-    auto group = [&](auto fast, int B) {
-        constexpr bool FAST = decltype(fast)::value;
-        step(fast, B, slot[0], slot[R - 1]);        // the roles rotate through statically indexed slots: no register moves
-        if (FAST || B - 1 >= first) step(fast, B - 1, slot[1], slot[0]);
-        if (R > 2 && (FAST || B - 2 >= first)) step(fast, B - 2, slot[R - 1], slot[1]);
-    };
-    load(std::false_type{}, last, slot[0]);
-    if (R > 2 && last - 1 >= first) load(std::false_type{}, last - 1, slot[1]);
-    int B = last;
-    const int fast_floor = (first > 1 ? first : 1) + 2 * (R - 1);   // lowest B whose group is all-FAST: its last load is B - 2(R-1)
-    for (; B >= first && (B + 1) * CK > n; B -= R) group(std::false_type{}, B);      // the group with the line's ragged end
-    for (; B >= fast_floor; B -= R) group(std::true_type{}, B);
-    for (; B >= first; B -= R) group(std::false_type{}, B);
-    pc_barrier();          // the consumer's last step
-}
-
-template <int CK, class Src>
-__device__ __forceinline__ void pc_consume(const Src &src, int n, int sg0, int sg1, int k1, const IirCoef &c,
-                                           double (*vcbuf)[CK][64], float *tw, int lane, long line0, int lines,
-                                           float *__restrict__ outT, const PackOut &po) {
-    typedef typename Src::raw_t raw_t;
-    constexpr int SB = CK / IIR_U;                          // 16-step tiles per super-block
-    struct Slot { raw_t s[CK]; };
-    constexpr int R = CK <= 16 ? 3 : 2;
-    Slot slot[R];
-    const int ll = lane >> 2, ch = lane & 3;                // line within the wave's 16, channel
-    const float initial_m = src.decode(src.fetch(k1 - 1));
-    double s1 = 0, s2 = 0, s3 = 0, s4 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;      // anticausal state
-    const int first = sg0 / CK, last = (sg1 + CK - 1) / CK - 1;
-    auto load = [&](auto fast, int B, Slot &o) {
-        const int kb = B * CK;
-        if (decltype(fast)::value || kb + CK <= n) {
-            const raw_t *r = src.row(kb);
-#pragma unroll
-            for (int u = 0; u < CK; ++u) o.s[u] = src.at(r, u);
-        } else {
-#pragma unroll
-            for (int u = 0; u < CK; ++u) o.s[u] = src.fetch(kb + u < n ? kb + u : 0);
-        }
-    };
-    load(std::false_type{}, last, slot[0]);
-    if (R > 2 && last - 1 >= first) load(std::false_type{}, last - 1, slot[1]);
-    if (k1 > sg1) {
-        // a segment's warm-up over [sg1, k1), unrecorded: sg1 is a super-block boundary here (only the last segment
-        // ends elsewhere, and it has no warm-up)
-        raw_t cur_s[IIR_U], nxt_s[IIR_U];
-        const int wend = (k1 + IIR_U - 1) / IIR_U, wbeg = sg1 / IIR_U;
-#pragma unroll
-        for (int u = 0; u < IIR_U; ++u) cur_s[u] = src.fetch((wend - 1) * IIR_U + u < k1 ? (wend - 1) * IIR_U + u : sg1);
-        for (int b = wend - 1; b >= wbeg; --b) {
-            const int kb = b * IIR_U;
-#pragma unroll
-            for (int u = 0; u < IIR_U; ++u) nxt_s[u] = src.fetch(b > wbeg ? kb - IIR_U + u : sg1);
-#pragma unroll
-            for (int u = IIR_U - 1; u >= 0; --u) {
-                const int k = kb + u;
-                if (k < k1) {
-                    const int j = k1 - 1 - k;
-                    const double s0 = (double)src.decode(cur_s[u]);
-                    double acc;
-                    if (j < 4) acc = iir_edge_step(j, s0, s1, s2, s3, v1, v2, v3, c.n_m, c.d_m, c.bd_m, initial_m);
-                    else acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
-                    s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-                    v4 = v3; v3 = v2; v2 = v1; v1 = acc;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < IIR_U; ++u) cur_s[u] = nxt_s[u];
-        }
-    }
-    pc_barrier();          // the producer's first step
-    // 16 lines x 16 steps of the tile, transposed: lane -> (line = i*4 + lane/16, step = lane%16)
-    auto write_tile = [&](auto fast, int kb) {
-        constexpr bool FAST = decltype(fast)::value;
-        // the tile is private to this wave: a wave-level fence suffices
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tl = i * 4 + (lane >> 4), kk = lane & 15;
-            const long line = line0 + tl;
-            const int k = kb + kk;
-            if (line < lines && (FAST || k < n)) {
-                const float4 v = *(const float4 *)&tw[tl * (IIR_U * 4 + 4) + kk * 4];
-                if (po.write_map) {      // written once, read by the next pass long after it has left the caches: non-temporal
-                    typedef float mm_f4 __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(mm_f4{v.x, v.y, v.z, v.w}, (mm_f4 *)&outT[(line * (long)n + k) * 4]);
-                }
-                if (po.out && line >= po.line_lo && line < po.line_hi && k >= po.k_lo && k < po.k_hi)
-                    __builtin_nontemporal_store(pack_rgba8(v), (unsigned *)(po.out + (line - po.line_lo) * po.row_stride + (long)(k - po.k_lo) * 4));
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    // One step: loads of super-block B-(R-1) (slot far); anticausal steps of B (slot cur) plus the causal values the producer
-    // left in buffer B & 1, a tile at a time; barrier.  FAST: B lies at least a tile inside [.., k1) -- no edge steps, no bounds.
-    auto step = [&](auto fast, int B, Slot &cur, Slot &far) {
-        constexpr bool FAST = decltype(fast)::value;
-        if (FAST || B - (R - 1) >= first) load(fast, B - (R - 1), far);
-        double (*vc)[64] = vcbuf[B & 1];
-#pragma unroll
-        for (int sb = SB - 1; sb >= 0; --sb) {
-            const int kb = B * CK + sb * IIR_U;
-            if (FAST || kb + 2 * IIR_U <= k1) {
-#pragma unroll
-                for (int ua = IIR_U - 1; ua >= 0; --ua) {
-                    const double s0 = (double)src.decode(cur.s[sb * IIR_U + ua]);
-                    const double acc = iir_step_anticausal<Src::finite>(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
-                    tw[ll * (IIR_U * 4 + 4) + ua * 4 + ch] = (float)(vc[sb * IIR_U + ua][lane] + acc);   // transfer_pixels, gauss.c:117-124
-                    s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-                    v4 = v3; v3 = v2; v2 = v1; v1 = acc;
-                }
-                write_tile(fast, kb);
-            } else if (kb < n) {
-#pragma unroll
-                for (int u = IIR_U - 1; u >= 0; --u) {
-                    const int k = kb + u;
-                    if (k < n) {
-                        const int j = k1 - 1 - k;                    // steps from the end (of the line, or of the warm-up)
-                        const double s0 = (double)src.decode(cur.s[sb * IIR_U + u]);
-                        double acc;
-                        if (j < 4) acc = iir_edge_step(j, s0, s1, s2, s3, v1, v2, v3, c.n_m, c.d_m, c.bd_m, initial_m);
-                        else acc = iir_step(s0, s1, s2, s3, s4, v1, v2, v3, v4, c.n_m, c.d_m);
-                        tw[ll * (IIR_U * 4 + 4) + u * 4 + ch] = (float)(vc[sb * IIR_U + u][lane] + acc);
-                        s4 = s3; s3 = s2; s2 = s1; s1 = s0;
-                        v4 = v3; v3 = v2; v2 = v1; v1 = acc;
-                    }
-                }
-                write_tile(std::false_type{}, kb);
-            }
-        }
-        pc_barrier();
-    };
-    auto group = [&](auto fast, int B) {
-        constexpr bool FAST = decltype(fast)::value;
-        step(fast, B, slot[0], slot[R - 1]);
-        if (FAST || B - 1 >= first) step(fast, B - 1, slot[1], slot[0]);
-        if (R > 2 && (FAST || B - 2 >= first)) step(fast, B - 2, slot[R - 1], slot[1]);
-    };
-    int B = last;
-    const int fast_floor = first + 2 * (R - 1);            // lowest B whose group is all-FAST: its last load is B - 2(R-1)
-    for (; B >= first && (B + 1) * CK + IIR_U > k1; B -= R) group(std::false_type{}, B);      // the group at the line's end
-    for (; B >= fast_floor; B -= R) group(std::true_type{}, B);
-    for (; B >= first; B -= R) group(std::false_type{}, B);
-}
-
-template <int CK, class Src>
-__global__ void __launch_bounds__(128, 2) k_iir_anticausal_pc(Src in, const double *__restrict__ ckpt, float *__restrict__ outT,
-                                                           LineArgs g, IirCoef c, PackOut po) {
-    __shared__ double vcbuf[2][CK][64];                    // the producer's causal values: [super-block & 1][step][lane]
-    __shared__ float tile[16 * (IIR_U * 4 + 4)];           // the consumer's staging tile: 16 lines x 16 steps x 4 channels
-    const unsigned sgi = blockIdx.x / g.lane_blocks, lb = blockIdx.x % g.lane_blocks;     // lane_blocks: 64-lane groups here
-    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
-    const long L = (long)lb * 64 + lane;
-    const long stride = (long)g.lines * 4;
-    const long line0 = ((long)lb * 64) >> 2;               // first line of this workgroup
-    const long Lc = L < stride ? L : 0;      // idle lanes of the last group shadow lane 0; their tile rows are never written out
-    const int s0 = (int)sgi * g.seg, s1 = min(g.n, s0 + g.seg), k1 = s1 < g.n ? min(g.n, s1 + g.halo) : g.n;
-    const Src src = in.for_lane(Lc);
-    // both roles pass the same number of barriers: one per super-block of the segment, plus one
-    if (role == 0) pc_produce<CK>(src, ckpt, (unsigned)stride, (unsigned)Lc, g.n, s0, s1, c, vcbuf, lane);
-    else pc_consume<CK>(src, g.n, s0, s1, k1, c, vcbuf, tile, lane, line0, g.lines, outT, po);
-}
-
 // How to split lines of n steps, `lines` of them, for a recurrence of standard deviation sigma.
 // Off by default -- one segment, every value identical to the reference's: a warmed-up segment start
 // agrees with the full sweep only to the recurrence's own rounding-noise floor (~1e-14 relative in
@@ -890,17 +637,17 @@ __global__ void __launch_bounds__(128, 2) k_iir_anticausal_pc(Src in, const doub
 // + halo steps, at a rate set by the waves a SIMD holds: 1024 SIMDs, and a second wave hides the
 // first one's scalar and memory instructions), =N forces N.  Measured at 16384^2, sigma 20 px: 8.85 ->
 // 8.13 ms with two segments; the gain is large only for frames too small to give every SIMD a wave.
-LineArgs plan_segments(int n, int lines, float sigma, int align) {      // align: the checkpoint interval (segment starts and halos are multiples of it)
-    LineArgs g{n, lines, ((n + align - 1) / align) * align, 0, (unsigned)(((long)lines * 4 + 255) / 256)};
+LineArgs plan_segments(int n, int lines, float sigma) {
+    LineArgs g{n, lines, ((n + IIR_U - 1) / IIR_U) * IIR_U, 0, (unsigned)(((long)lines * 4 + 255) / 256)};
     const char *env = getenv("MMHIP_GAUSS_SEGMENTS");
     if (!env || !*env) return g;
     const int forced = strcmp(env, "auto") ? atoi(env) : 0;
     if (strcmp(env, "auto") && forced <= 1) return g;
-    const int halo = (((int)ceil(22.7 * (double)sigma) + 2 + align - 1) / align) * align;
+    const int halo = (((int)ceil(22.7 * (double)sigma) + 2 + IIR_U - 1) / IIR_U) * IIR_U;
     const double waves = (double)g.lane_blocks * 4.0;
     double best = 0.0;
     for (int ns = 1; ns <= 64; ++ns) {
-        const int seg = (((n + ns - 1) / ns + align - 1) / align) * align;
+        const int seg = (((n + ns - 1) / ns + IIR_U - 1) / IIR_U) * IIR_U;
         if (ns > 1 && (seg < halo || (long)seg * (ns - 1) >= n)) break;     // too short to pay / empty last segment
         const double per_simd = ceil(waves * ns / 1024.0);
         const double cost = (double)(seg + (ns > 1 ? halo : 0)) * std::max(1.0, 0.53 * per_simd);
@@ -1135,48 +882,30 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
     }
     const int hn = y1 - y0;
     // the scan kernels index a block of rows with 32-bit element offsets (MapSrc::at)
-    if ((long)std::max(w, hn) * 4 * 36 * 8 >= (1L << 32)) { *err = "gaussian_blur: frame too large for the scan kernels"; return -1; }
+    if ((long)std::max(w, hn) * 4 * 20 * 8 >= (1L << 32)) { *err = "gaussian_blur: frame too large for the scan kernels"; return -1; }
     // vertical pass first (gauss.c:155-201): lines = columns, n = rows of the window; result transposed
     // into mapT[w][hn][4].  Its two sweeps read the input where it lies: the float map, or --
     // identity mapping -- the drawable itself: no intermediate map, 4 instead of 16 B/px.
-    // Kernel shape (A/B switches): MMHIP_GAUSS_PC=0 takes the one-wave anticausal kernel (two chains per lane, checkpoints
-    // every 16 steps); default is the producer / consumer pair with a checkpoint every MMHIP_GAUSS_CK = 32 (or 16) steps.
-    const char *e_pc = getenv("MMHIP_GAUSS_PC"), *e_ck = getenv("MMHIP_GAUSS_CK");
-    const bool pc = !(e_pc && atoi(e_pc) == 0);
-    const int ckint = !pc ? IIR_U : (e_ck && atoi(e_ck) == 16 ? 16 : 32);
-    auto run_pass = [&](const char *causal_name, const char *anti_name, auto src, int n, int lines, float sigma, float *dst, const PackOut &po) {
-        typedef decltype(src) Src;
-        const LineArgs g = plan_segments(n, lines, sigma, ckint);
-        const unsigned blocks = g.lane_blocks * segment_count(g);
-        LineArgs gp = g;                                   // the pair kernel: a workgroup (two waves) per 64 lanes
-        gp.lane_blocks = (unsigned)(((long)lines * 4 + 63) / 64);
-        const unsigned pblocks = gp.lane_blocks * segment_count(g);
-        if (!pc) {
-            ws.timed_launch(causal_name, s, [&] { k_iir_causal<IIR_U, Src><<<blocks, 256, 0, s>>>(src, scratch, g, c); });
-            ws.timed_launch(anti_name, s, [&] { k_iir_anticausal_T<Src><<<blocks, 256, 0, s>>>(src, scratch, dst, g, c, po); });
-        } else if (ckint == 16) {
-            ws.timed_launch(causal_name, s, [&] { k_iir_causal<16, Src><<<blocks, 256, 0, s>>>(src, scratch, g, c); });
-            ws.timed_launch(anti_name, s, [&] { k_iir_anticausal_pc<16, Src><<<pblocks, 128, 0, s>>>(src, scratch, dst, gp, c, po); });
-        } else {
-            ws.timed_launch(causal_name, s, [&] { k_iir_causal<32, Src><<<blocks, 256, 0, s>>>(src, scratch, g, c); });
-            ws.timed_launch(anti_name, s, [&] { k_iir_anticausal_pc<32, Src><<<pblocks, 128, 0, s>>>(src, scratch, dst, gp, c, po); });
-        }
-    };
     find_iir_constants(c, vs);
     {
-        const PackOut nopack{nullptr, 0, 0, 0, 0, 0, 1};
+        const LineArgs g = plan_segments(hn, w, vs);
+        const unsigned blocks = g.lane_blocks * segment_count(g);
         if (in.kind == IMG_FLOATMAP || !identity) {
             const MapSrc src{(in.kind == IMG_FLOATMAP ? (const float *)in.data : out_map) + (long)y0 * w * 4, (unsigned)w * 4u, 0u};
-            run_pass("iir_causal_vertical", "iir_anticausal_vertical", src, hn, w, vs, mapT, nopack);
+            ws.timed_launch("iir_causal_vertical", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_vertical", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1}); });
         } else {
             const DrawableSrc src{(const uint32_t *)in.data + (long)y0 * in.w, (unsigned)in.w, 0u, 0};
-            run_pass("iir_causal_vertical", "iir_anticausal_vertical", src, hn, w, vs, mapT, nopack);
+            ws.timed_launch("iir_causal_vertical", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_vertical", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, mapT, g, c, PackOut{nullptr, 0, 0, 0, 0, 0, 1}); });
         }
     }
     // horizontal pass (gauss.c:203-252): in mapT the window's rows are the "columns"; transposing again
     // restores the original layout, written to rows [y0, y1) of out_map
     find_iir_constants(c, hs);
     {
+        const LineArgs g = plan_segments(w, hn, hs);
+        const unsigned blocks = g.lane_blocks * segment_count(g);
         // lines of this pass are rows of the window [y0, y1), steps are columns
         PackOut po{nullptr, 0, 0, 0, 0, 0, 1};
         if (direct && direct->out && direct->first_row >= y0 && direct->first_row + direct->num_rows <= y1) {
@@ -1187,10 +916,12 @@ int gaussian_blur(const HNativeRec &rec, const std::vector<HImageDesc> &images, 
         }
         if (in.kind == IMG_FLOATMAP) {
             const MapSrc src{mapT, (unsigned)hn * 4u, 0u};
-            run_pass("iir_causal_horizontal", "iir_anticausal_horizontal", src, w, hn, hs, out_map + (long)y0 * w * 4, po);
+            ws.timed_launch("iir_causal_horizontal", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_horizontal", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po); });
         } else {      // the first pass read bytes: its output is finite
             const FiniteMapSrc src{mapT, (unsigned)hn * 4u, 0u};
-            run_pass("iir_causal_horizontal", "iir_anticausal_horizontal", src, w, hn, hs, out_map + (long)y0 * w * 4, po);
+            ws.timed_launch("iir_causal_horizontal", s, [&] { k_iir_causal<<<blocks, 256, 0, s>>>(src, scratch, g, c); });
+            ws.timed_launch("iir_anticausal_horizontal", s, [&] { k_iir_anticausal_T<<<blocks, 256, 0, s>>>(src, scratch, out_map + (long)y0 * w * 4, g, c, po); });
         }
     }
     if (hipGetLastError() != hipSuccess) { *err = "gaussian_blur: kernel launch failed"; return -1; }
