@@ -282,7 +282,8 @@ struct Generator {
                     name = "mmf_pow_f32";
                 if (opt.fast_math_exact && !strcmp(cn, "hypot") && r.args.size() == 2 && r.args[0].type() == Ty::Float &&
                     r.args[1].type() == Ty::Float) {
-                    name = "mm_hypot_ff";
+                    // glibc's own arithmetic for two floats (mm_fastmath.h); a double-typed result keeps the earlier form
+                    name = lhs && lhs->type == Ty::Float ? "mmf_hypot_f32" : "mm_hypot_ff";
                 }
                 std::string s = name + "(";
                 for (size_t i = 0; i < r.args.size(); ++i) s += (i ? "," : "") + prim(r.args[i], sl);
@@ -1099,6 +1100,7 @@ struct Generator {
                "#define MMF_SIN_SLOW(a) sin((a))\n#define MMF_COS_SLOW(a) cos((a))\n"
                "#define MMF_LDEXP(a, e) __builtin_ldexp((a), (e))\n#define MMF_EXP_SLOW(a) exp((a))\n#define MMF_LOG_SLOW(a) log((a))\n"
                "#define MMF_POW_SLOW(a, b) pow((a), (b))\n"
+               "#define MMF_SQRT(a) __builtin_sqrt((a))\n#define MMF_HYPOT_SLOW(a, b) hypot((a), (b))\n"
                // mm_glibcf.h (glibc's float algorithms for the complex ops); float sqrt / division are the correctly
                // rounded device ones, double sqrt is the compiler's correctly rounded expansion
                "#define MMQ_FN static __device__ __forceinline__\n#define MMQ_TABLE static __device__ const\n"

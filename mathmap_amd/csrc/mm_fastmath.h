@@ -284,6 +284,47 @@ MMF_FN float mmf_pow_f32(float x, float y) {
     return (float)r;
 }
 
+// ---- hypot of two float arguments ---------------------------------------------------------------------
+// (float)hypot((double)x, (double)y) as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/e_hypot.c; the x86-64 build has no
+// FMA variant: its kernel is h = sqrt(ax^2 + ay^2) followed by one correction step in plain double arithmetic).  For
+// floats widened to double the squares are exact and neither overflow nor underflow, so none of its scaling branches
+// is reachable; what remains is kernel(ax, ay) -- and ax + ay when ay <= 2^-54 ax.  The correction moves h by about an
+// ulp of double and matters for the float only when h lies within a few ulps of a float rounding boundary (once in
+// 2^26 calls): everywhere else (float)h is already the result, and the division is skipped.
+#ifndef MMF_HYPOT_SLOW
+#define MMF_HYPOT_SLOW(a, b) hypot((a), (b))
+#define MMF_SQRT(a) sqrt((a))
+#endif
+MMF_FN float mmf_hypot_f32(float x, float y) {
+    const double fx = (double)x, fy = (double)y;
+    // ax^2 + ay^2 in either order is the same sum; with ay <= 2^-54 ax it is ax^2 and its root ax = ax + ay rounded:
+    // glibc's early exit needs no test here
+    double h = MMF_SQRT(fx * fx + fy * fy);
+    union { double d; unsigned long long u; } b;
+    b.d = h;
+    const unsigned low = (unsigned)b.u & 0x1fffffffu;
+    const unsigned d_tie = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;
+    if (d_tie <= 8u || !(h <= 1.7976931348623157e308)) {
+        if (!(h <= 1.7976931348623157e308)) return (float)MMF_HYPOT_SLOW(fx, fy);      // inf, NaN
+        const double gx = MMF_FABS(fx), gy = MMF_FABS(fy);
+        const double ax = gx < gy ? gy : gx, ay = gx < gy ? gx : gy;
+        if (ax >= ay * 0x1p54) return (float)(ax + ay);    // glibc: ax >= ay / EPS (a power of two: the same comparison)
+        // the kernel's correction (no contraction: the reference's build has none either)
+        double t1, t2;
+        if (h <= 2.0 * ay) {
+            const double delta = h - ay;
+            t1 = ax * (2.0 * delta - ax);
+            t2 = (delta - 2.0 * (ax - ay)) * delta;
+        } else {
+            const double delta = h - ax;
+            t1 = 2.0 * delta * (ax - 2.0 * ay);
+            t2 = (4.0 * delta - ay) * ay + delta * delta;
+        }
+        h -= (t1 + t2) / (2.0 * h);
+    }
+    return (float)h;
+}
+
 // Double-in, double-out variants with the range tests, for the float-complex functions.
 MMF_FN double mmf_exp_any(double xd) { return (MMF_FABS(xd) <= 700.0) ? mmf_exp_d(xd) : MMF_EXP_SLOW(xd); }
 MMF_FN double mmf_log_any(double xd) {

@@ -442,7 +442,9 @@ PROBES = [
     # sin / cos of a float: mm_fastmath.h, verified equal to glibc for every float below 2^22
     ("sin(u*7)", "sin", 0), ("cos(v*7)", "cos", 0), ("sin(u*3000000+v)", "sin wide", 0), ("cos(v*4000000+u)", "cos wide", 0),
     ("sin(u*1000000000)", "sin beyond 2^22 (OCML)", 1), ("tan(u)", "tan", 1), ("atan(u*9, v*9)", "atan2", 1),
-    ("exp(u*3)", "exp", 0), ("exp(v*120)", "exp wide", 0), ("log(abs(u)+0.001)", "log", 0), ("log(abs(u*v)*1000000)", "log wide", 0), ("abs(ri:[u,v])", "hypot", 1),
+    ("exp(u*3)", "exp", 0), ("exp(v*120)", "exp wide", 0), ("log(abs(u)+0.001)", "log", 0), ("log(abs(u*v)*1000000)", "log wide", 0),
+    # hypot: glibc's own arithmetic for two floats (mm_fastmath.h)
+    ("abs(ri:[u,v])", "hypot", 0), ("abs(ri:[u*1000,v*0.001])", "hypot wide", 0),
     ("asin(u)", "asin", 1), ("acos(v)", "acos", 1), ("(abs(u)+0.01)^(v*3)", "pow", 1), ("(abs(u*v)+0.5)^2", "pow int", 0), ("(abs(u)*40+0.1)^(v*9-2)", "pow wide", 1),
     ("sinh(u*2)", "sinh", 1), ("cosh(v*2)", "cosh", 1), ("tanh(u*2)", "tanh", 1), ("u % 0.37", "fmod", 0),
 ]

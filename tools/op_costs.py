@@ -13,7 +13,7 @@ OPS = ["x*y", "sin(x*y*9)", "cos(x*y*9)", "tan(x*y)", "asin(x*y)", "acos(x*y)", 
        "x/(y+2)", "exp(x*y*4)", "log(x*y+1.5)", "(x+1.5)^(y*3)", "sqrt(x*y+1.5)", "sinh(x*y*3)", "tanh(x*y*3)", "(x*y)%0.37",
        "floor(x*y*9)", "abs(exp(ri:[x, y*6]))", "abs(log(ri:[x, y]))", "abs(ri:[x,y]^ri:[1.3,0.4])", "abs(sin(ri:[x*3,y]))",
        "abs(sqrt(ri:[x,y]))", "log(abs(ri:[x,y])+0.001)", "log(abs(ri:[x,y])+0.001)+atan(y,x)", "(log(ri:[x,y]))[0]",
-       "(log(ri:[x,y]))[1]"]
+       "(log(ri:[x,y]))[1]", "r", "a", "r+a", "sin(r / 0.04) * 0.05 + a", "cos(a) * r", "cos(a) * r + sin(a) * r"]
 
 
 def main():

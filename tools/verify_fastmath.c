@@ -21,7 +21,9 @@ enum { NTHREADS = 8 };
 static uint32_t stride = 1;
 static uint32_t limit_bits;
 typedef struct { uint64_t checked, bad_sin, bad_cos, checked_exp, bad_exp, checked_log, bad_log, checked_pow, bad_pow;
-                 uint32_t first_bad, first_bad_exp, first_bad_log, first_bad_pow_x, first_bad_pow_y; int tid; } acc_t;
+                 uint64_t checked_hypot, bad_hypot;
+                 uint32_t first_bad, first_bad_exp, first_bad_log, first_bad_pow_x, first_bad_pow_y;
+                 uint32_t first_bad_hypot_x, first_bad_hypot_y; int tid; } acc_t;
 static uint64_t pow_pairs = 0;      /* random (x, y) pairs per thread, argv[2] */
 
 static inline uint64_t splitmix(uint64_t *s) {
@@ -61,6 +63,29 @@ static void *worker(void *p) {
         const float x = float_of((uint32_t)u);
         if (bits_of((float)log((double)x)) != bits_of(mmf_log_f32(x))) { if (!a->bad_log) a->first_bad_log = bits_of(x); ++a->bad_log; }
         ++a->checked_log;
+    }
+    /* hypot: two arguments cannot be enumerated -- random pairs in four mixes (any two finite floats; the same binade;
+     * y a few to 30 binades below x, where x^2 + y^2 comes close to the square of a rounding boundary; small integers,
+     * Pythagorean triples among them), the function restates glibc's own arithmetic */
+    {
+        uint64_t seed = 0x7654321ULL + (uint64_t)a->tid * 0x9e3779b9ULL;
+        for (uint64_t n = 0; n < pow_pairs; ++n) {
+            const uint64_t z = splitmix(&seed);
+            float x, y;
+            switch (n & 3) {
+                case 0: x = float_of((uint32_t)(z & 0xffffffffu)); y = float_of((uint32_t)(z >> 32)); break;
+                case 1: x = float_of(0x3f800000u | (uint32_t)(z & 0x7fffffu)); y = float_of(0x3f800000u | (uint32_t)((z >> 32) & 0x7fffffu)); break;
+                case 2: x = float_of(0x3f800000u | (uint32_t)(z & 0x7fffffu));
+                        y = float_of(((127u - (uint32_t)((z >> 56) % 31)) << 23) | (uint32_t)((z >> 24) & 0x7fffffu)); break;
+                default: x = (float)(int)(z & 0xfff); y = (float)(int)((z >> 32) & 0xfff); break;
+            }
+            const float want = (float)hypot((double)x, (double)y), got = mmf_hypot_f32(x, y);
+            if (bits_of(want) != bits_of(got) && !(want != want && got != got)) {
+                if (!a->bad_hypot) { a->first_bad_hypot_x = bits_of(x); a->first_bad_hypot_y = bits_of(y); }
+                ++a->bad_hypot;
+            }
+            ++a->checked_hypot;
+        }
     }
     /* pow: two arguments cannot be enumerated -- random pairs in four mixes (any positive x with any y;
      * x in [1/4, 4] with |y| < 64; small integer and half-integer y; x within a few thousand ulps of 1 with
@@ -118,12 +143,20 @@ int main(int argc, char **argv) {
         cp += acc[i].checked_pow; bp += acc[i].bad_pow;
         if (!fpx && acc[i].bad_pow) { fpx = acc[i].first_bad_pow_x; fpy = acc[i].first_bad_pow_y; }
     }
-    printf("{\"checked\": %llu, \"stride\": %u, \"sin_mismatches\": %llu, \"cos_mismatches\": %llu, \"first_bad_bits\": \"0x%08x\", "
+    uint64_t ch = 0, bh = 0;
+    uint32_t fhx = 0, fhy = 0;
+    for (int i = 0; i < NTHREADS; ++i) {
+        ch += acc[i].checked_hypot; bh += acc[i].bad_hypot;
+        if (!fhx && !fhy && acc[i].bad_hypot) { fhx = acc[i].first_bad_hypot_x; fhy = acc[i].first_bad_hypot_y; }
+    }
+    printf("{\"hypot_random_pairs_checked\": %llu, \"hypot_mismatches\": %llu, \"hypot_first_bad_bits\": \"0x%08x 0x%08x\", ",
+           (unsigned long long)ch, (unsigned long long)bh, fhx, fhy);
+    printf("\"checked\": %llu, \"stride\": %u, \"sin_mismatches\": %llu, \"cos_mismatches\": %llu, \"first_bad_bits\": \"0x%08x\", "
            "\"exp_checked\": %llu, \"exp_mismatches\": %llu, \"exp_first_bad_bits\": \"0x%08x\", "
            "\"log_checked\": %llu, \"log_mismatches\": %llu, \"log_first_bad_bits\": \"0x%08x\", "
            "\"pow_random_pairs_checked\": %llu, \"pow_mismatches\": %llu, \"pow_first_bad_bits\": \"0x%08x 0x%08x\"}\n",
            (unsigned long long)checked, stride, (unsigned long long)bs, (unsigned long long)bc, first,
            (unsigned long long)ce, (unsigned long long)be, fe, (unsigned long long)cl, (unsigned long long)bl, fl,
            (unsigned long long)cp, (unsigned long long)bp, fpx, fpy);
-    return (bs || bc || be || bl) ? 1 : 0;     /* pow mismatches are reported, not fatal: it is not enumerable */
+    return (bs || bc || be || bl) ? 1 : 0;     /* pow / hypot mismatches are reported, not fatal: not enumerable */
 }
