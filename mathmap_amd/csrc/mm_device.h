@@ -362,15 +362,16 @@ MM_DEV mm_complex cgamma(mm_complex zf) {
                              0.008782877493061, -1.899030264e-6, 1.946335e-9};
     mm_dc z = mm_widen(zf);
     mm_dc denom = mm_dcmake(1.0, 0.0);
-    int guard = 0;
-    // the reference recurses on float-rounded arguments; unrolled here as a loop
-    while (z.re < 0.0 && guard++ < 64) {
-        int flr = (int)-floor(z.re);
-        mm_dc d = mm_dcmake(1.0, 0.0);
-        for (int n = 0; n < flr; ++n) d = mm_dcmul(d, mm_dcmake(z.re + n, z.im));
-        denom = mm_dcmul(denom, d);
-        mm_complex zn = mm_cmake((float)(z.re + flr), (float)z.im);   // argument passes through float
-        z = mm_widen(zn);
+    bool reflected = false;
+    // creal(z) < 0 (spec_func.c:44-53): denom = prod (z + n), n < flr = -floor(creal z), then cgamma(z + flr) / denom.  z is a
+    // complex *float* there: z + n and z + flr are float additions (rounded to float), the factors multiply in double, and
+    // the inner call's result comes back as a complex float -- rounded -- before the double division.  z + flr lies in
+    // [0, 1]: one level.
+    if (z.re < 0.0) {
+        const int flr = (int)-floor(z.re);
+        for (int n = 0; n < flr; ++n) denom = mm_dcmul(denom, mm_dcmake((double)(zf.re + (float)n), z.im));
+        z = mm_widen(mm_cmake(zf.re + (float)flr, zf.im));
+        reflected = true;
     }
     mm_dc w = mm_dcmake(z.re - 1.0, z.im);
     mm_dc s = mm_dcmake(coeff[0], 0.0), H = mm_dcmake(1.0, 0.0);
@@ -381,7 +382,8 @@ MM_DEV mm_complex cgamma(mm_complex zf) {
     mm_dc e = mm_dcexp(mm_dcmake(-w.re - 5.5, -w.im));
     mm_dc p = mm_dcpow(mm_dcmake(w.re + 5.5, w.im), mm_dcmake(w.re + 0.5, w.im));
     mm_dc r = mm_dcmul(mm_dcmul(mm_dcmake(2.506628274631 * e.re, 2.506628274631 * e.im), p), s);
-    return mm_narrow(mm_dcdiv(r, denom));
+    if (!reflected) return mm_narrow(r);
+    return mm_narrow(mm_dcdiv(mm_widen(mm_narrow(r)), denom));
 }
 
 // ---- colours (new_template.c.in:71-77, opmacros.h:147-154,176-181) --------------------------

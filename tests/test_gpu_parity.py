@@ -478,12 +478,14 @@ def test_real_math_float_ulps(expr, label, max_ulp):
 
 
 # (expression, max float ulps allowed per component over ALL finite results).  0: the device runs glibc's own
-# float algorithm (mm_glibcf.h, verified bit for bit against the host libm by tools/verify_glibcf.c); the
-# only cgamma (the reference's own spec_func.c, restated in double) is held to an error bound instead.
+# float algorithm (mm_glibcf.h, verified bit for bit against the host libm by tools/verify_glibcf.c).  cgamma (the
+# reference's own spec_func.c: double complex inside, with the float roundings of its `creal(z) < 0` branch) is held
+# to 1 ulp -- its double exp / log / sincos / atan2 / hypot are this project's or OCML's, not glibc's; measured: every
+# value of the three probes identical (tools/gamma_probe.py).
 COMPLEX_PROBES = [("exp(z)", 0), ("log(z)", 0), ("sqrt(z)", 0), ("sin(z)", 0), ("cos(z)", 0), ("tan(z)", 0),
                   ("z^ri:[1.3,0.4]", 0), ("ri:[0.3,-0.8]^z", 0), ("sinh(z)", 0), ("cosh(z)", 0), ("tanh(z)", 0), ("arg(z)", 0),
                   ("asin(z)", 0), ("acos(z)", 0), ("atan(z)", 0), ("asinh(z)", 0), ("acosh(z)", 0),
-                  ("atanh(z)", 0), ("gamma(z)", None)]
+                  ("atanh(z)", 0), ("gamma(z)", 1)]
 
 
 @pytest.mark.parametrize("expr,max_ulp", COMPLEX_PROBES, ids=[p[0] for p in COMPLEX_PROBES])
@@ -491,8 +493,7 @@ COMPLEX_PROBES = [("exp(z)", 0), ("log(z)", 0), ("sqrt(z)", 0), ("sin(z)", 0), (
 def test_complex_math_float_ulps(expr, max_ulp, scale):
     """float-complex functions in float-map mode (raw float outputs) over z = scale * (x + i y): device
     vs glibc.  For the functions restated after glibc (max_ulp = 0) every finite component must be
-    identical and the NaN / inf patterns must agree; the others (double internally, rounded once) are
-    held to a relative error bound at the 99.5th percentile."""
+    identical and the NaN / inf patterns must agree; cgamma may differ by one ulp in at most 1e-4 of the values."""
     w, h = 256, 256
     if expr == "arg(z)":
         src = "filter probe () z = ri:[x*%g, y*%g]; w = arg(z); rgba:[w, w, w, w] end" % (scale, scale)
@@ -502,16 +503,9 @@ def test_complex_math_float_ulps(expr, max_ulp, scale):
     inv = flt.invoke(w, h)
     got = render_device(inv, w, h, floatmap=True)
     want = CpuFilter(flt.ir_json_raw).render(w, h, floatmap=True)
-    if max_ulp is not None:
-        ulps = float_ulps(got[:, :, :2], want[:, :, :2])
-        assert ulps.max() <= max_ulp, "%s: max %d ulps, %d of %d values differ" % (expr, ulps.max(), (ulps > 0).sum(), ulps.size)
-        return
-    a, b = got[:, :, :2].astype(np.float64), want[:, :, :2].astype(np.float64)
-    finite = np.isfinite(a).all(axis=2) & np.isfinite(b).all(axis=2)
-    mag = np.maximum(np.hypot(b[..., 0], b[..., 1]), 1e-30)
-    err = np.hypot(a[..., 0] - b[..., 0], a[..., 1] - b[..., 1]) / mag
-    tol = 2e-5 if expr == "gamma(z)" else 4e-6   # |error| relative to |result|
-    assert np.percentile(err[finite], 99.5) < tol, "%s: p99.5 rel err %.3g" % (expr, np.percentile(err[finite], 99.5))
+    ulps = float_ulps(got[:, :, :2], want[:, :, :2])
+    assert ulps.max() <= max_ulp, "%s: max %d ulps, %d of %d values differ" % (expr, ulps.max(), (ulps > 0).sum(), ulps.size)
+    assert (ulps == 0).mean() >= 0.9999, "%s: only %.6f identical" % (expr, (ulps == 0).mean())
 
 
 @pytest.mark.parametrize("hdev,vdev", [(0.001, 0.001), (0.0012, 0.04), (0.05, 0.0009), (0.0, 0.02)])
