@@ -556,8 +556,27 @@ mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_i
                 number_native_closures(sub->body, again);
                 if (again.size() != closures.size()) throw CompileError("internal: closure numbering differs between imports");
                 Stmt *def = again[k].first;
-                if (def->parent) throw CompileError("a filter closure passed to a native filter inside a conditional or a loop is not supported");
+                // the conditionals around the closure, outermost first (a loop would make it one closure per iteration)
+                std::vector<std::pair<Stmt *, int>> nest;
+                for (const Stmt *c = def; c->parent; c = c->parent) {
+                    Stmt *p = c->parent;
+                    if (p->kind != Stmt::If) throw CompileError("a filter closure passed to a native filter inside a loop is not supported");
+                    const bool in_then = std::find(p->then_.begin(), p->then_.end(), c) != p->then_.end();
+                    nest.insert(nest.begin(), {p, in_then ? 0 : 1});
+                }
                 Gen g(*sub);
+                // The result: four variables, 0 at the top of the body, assigned next to the closure; each enclosing `if'
+                // gets exit phis that carry the value -- or, where the branch does not run and the native filter is not
+                // called either, the 0 -- to the top level (lower.cpp native_image_argument does the same)
+                CompVar *rv[4];
+                std::vector<Stmt *> inits;
+                for (int i = 0; i < 4; ++i) {
+                    rv[i] = g.temp(Ty::Float);
+                    inits.push_back(g.assign(rv[i], Rhs::F(0.0f))->def);
+                }
+                for (Stmt *st : inits) sub->body.erase(std::find(sub->body.begin(), sub->body.end(), st));
+                sub->body.insert(sub->body.begin(), inits.begin(), inits.end());
+                for (auto &lv : nest) g.reenter_if(lv.first, lv.second);
                 Primary rx, ry;
                 emit_closure_render_coordinates(g, again[k].second, again[k].second.factors.empty(), &rx, &ry);
                 Rhs call;
@@ -570,10 +589,9 @@ mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_i
                 CompVar *tv = g.temp(Ty::Tuple);
                 tv->tuple_len = 4;
                 g.assign(tv, call);
-                for (int i = 0; i < 4; ++i) {
-                    CompVar *c = g.temp(Ty::Float);
-                    sub->result[i] = g.assign_op(c, "TUPLE_NTH", {g.P(tv), Primary::I(i)});
-                }
+                for (int i = 0; i < 4; ++i) g.assign_op(rv[i], "TUPLE_NTH", {g.P(tv), Primary::I(i)});
+                for (size_t lv = 0; lv < nest.size(); ++lv) g.end_if();
+                for (int i = 0; i < 4; ++i) sub->result[i] = rv[i]->current;
                 for (auto &kv : shared.filters)
                     if (kv.second == def->rhs.filter && std::find(shared.called.begin(), shared.called.end(), kv.first) == shared.called.end())
                         shared.called.push_back(kv.first);

@@ -113,6 +113,13 @@ void Gen::start_if(Rhs cond) {
     blocks_.push_back(&s->then_);
 }
 
+void Gen::reenter_if(Stmt *s, int branch) {
+    assert(s->kind == Stmt::If);
+    frames_.push_back(Frame{s, false, branch, {}, {}});
+    parents_.push_back(s);
+    blocks_.push_back(branch == 0 ? &s->then_ : &s->else_);
+}
+
 void Gen::switch_branch() {
     Frame &f = frames_.back();
     assert(!f.is_while && f.branch == 0);

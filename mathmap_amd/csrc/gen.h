@@ -31,6 +31,9 @@ class Gen {
     void start_if(Rhs cond);
     void switch_branch();
     void end_if();
+    // continue emitting at the end of a branch (0 = then, 1 = else) of an `if' that already exists; closed by end_if(),
+    // which adds exit phis for what was assigned meanwhile
+    void reenter_if(Stmt *s, int branch);
     void start_while(CompVar *invariant);
     void end_while();
 

@@ -40,7 +40,9 @@ class Lowerer {
     int render_target_ = -1;        // >= 0: lower "closure #render_target_ applied at (x, y), t = 0" as the result
     int closure_counter_ = 0;       // closures numbered in the order their first native use is lowered
     bool target_done_ = false, in_target_body_ = false;
-    Value *target_result_[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the target closure's value: four variables set to 0 at the top of the body and assigned where the closure meets its
+    // native filter -- inside a conditional the construct's exit phis carry the value (or the 0) out to the top level
+    CompVar *target_var_[4] = {nullptr, nullptr, nullptr, nullptr};
     void native_image_argument(CompVar *image, bool stripped);
 
    private:
@@ -389,14 +391,10 @@ void Lowerer::native_image_argument(CompVar *image, bool stripped) {
     in_target_body_ = true;          // numbering must not depend on which closure is the target
     gen_filter(def->rhs.filter, &cargs, res);
     in_target_body_ = false;
-    for (int i = 0; i < 4; ++i) {
-        target_result_[i] = res[i]->current;
-        const Stmt *d = target_result_[i] ? target_result_[i]->def : nullptr;
-        // the value has to exist at the top level of the body: a top-level statement, or an exit / entry phi of a
-        // top-level `if' / `while' (a phi's parent is the construct it belongs to)
-        const Stmt *scope = d ? (d->kind == Stmt::Phi && d->parent ? d->parent->parent : d->parent) : nullptr;
-        if (scope) throw CompileError("a filter closure passed to a native filter inside a conditional is not supported");
-    }
+    // Inside a conditional (render_image runs when the native call does: only in the branch taken) the assignment below
+    // gets an exit phi per enclosing `if': the closure's value where the branch runs, the initial 0 where it does not --
+    // and there the native filter is not called either (its record stays unexecuted), so the map is not even rendered.
+    for (int i = 0; i < 4; ++i) g_.assign(target_var_[i], Rhs::V(res[i]->current));
     target_done_ = true;
 }
 
@@ -689,11 +687,16 @@ void Lowerer::run_function(Filter *f) {
 
 void Lowerer::run(Filter *f) {
     CompVar *res[4];
+    if (render_target_ >= 0)
+        for (int i = 0; i < 4; ++i) {
+            target_var_[i] = g_.temp(Ty::Float);
+            g_.assign(target_var_[i], Rhs::F(0.0f));
+        }
     gen_filter(f, nullptr, res);
     for (int i = 0; i < 4; ++i) code_.result[i] = res[i]->current;
     if (render_target_ >= 0) {
         if (!target_done_) throw CompileError("internal: closure render target not reached");
-        for (int i = 0; i < 4; ++i) code_.result[i] = target_result_[i];
+        for (int i = 0; i < 4; ++i) code_.result[i] = target_var_[i]->current;
     }
 }
 

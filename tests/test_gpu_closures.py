@@ -53,6 +53,48 @@ end
 """
 
 
+# closures that meet their native filter inside conditionals (two levels; the condition is a user value, so the
+# branches survive into the kernel): render_image runs where the native call runs
+CONDITIONAL = INNER + """
+filter outer (image in, float s: 0-1 (0.03), int mode: 0-2 (%d))
+  if mode > 0 then
+    if mode > 1 then
+      b = gaussian_blur(inner(in, 0.5 + t), s * 2, s);
+      b(xy) * 0.5
+    else
+      b = gaussian_blur(inner(in, 0.75), s, s);
+      b(xy)
+    end
+  else
+    in(xy)
+  end
+end
+"""
+
+
+def test_closure_handed_to_a_native_filter_inside_a_conditional():
+    """Every mode against the oracle, and against the same blur written without the conditional."""
+    w, h = 160, 96
+    img = F.synthetic_image(w, h, seed=3)
+    flt, inv = make_invocation(CONDITIONAL % 1, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for mode, k, sx, gain in ((0, None, None, None), (1, "0.75", 1, 1.0), (2, "0.5 + t", 2, 0.5)):
+        inv.set("mode", mode)
+        got = inv.render(t=0.25)
+        want = cf.render(w, h, uservals={"mode": mode}, images={"in": img}, t=0.25)
+        assert np.array_equal(got, want), (mode, stats(got, want))
+        if mode:
+            flat = INNER + "filter flat (image in, float s: 0-1 (0.03)) b = gaussian_blur(inner(in, %s), s * %d, s); b(xy) * %g end" % (k, sx, gain)
+            _, fi = make_invocation(flat, w, h, {}, {"in": img})
+            assert np.array_equal(got, fi.render(t=0.25)), mode
+        else:
+            _, ii = make_invocation("ident", w, h, {}, {"in": img})
+            assert np.array_equal(got, ii.render())
+        # the variant with the user values baked in (the conditionals fold away) renders the same bytes
+        _, si = make_invocation(CONDITIONAL % 1, w, h, {"mode": mode}, {"in": img}, specialize=True)
+        assert np.array_equal(si.render(t=0.25), got), mode
+
+
 @pytest.mark.parametrize("name,src,tol", [("blur", BLUR_OF_CLOSURE, 0), ("render", RENDER_OF_CLOSURE, 0),
                                           ("two", TWO_CLOSURES, 0)])
 def test_native_filter_on_closure_image(name, src, tol):
@@ -95,14 +137,15 @@ def test_closure_arguments_are_values_of_the_current_frame_and_its_body_runs_at_
     assert np.array_equal(i2.render(t=0.9, frame=3), got)
 
 
-@pytest.mark.parametrize("name", ["blur", "render", "two", "timed_arg"])
+@pytest.mark.parametrize("name", ["blur", "render", "two", "timed_arg", "conditional_else", "conditional_then"])
 def test_closure_images_for_native_filters_through_the_reference_abi(name):
     """The same through gen_and_load_hip_code: the importer finds the closure images that reach native filters in the
     reference-layout IR, builds each one's render code from the main filter's code plus a call of the closure's own
     filter_code (abi_backend.cpp), and calc_lines must deliver the standalone tier's frame byte for byte."""
     import ctypes as C
     from mathmap_amd._lib import selftest_lib
-    src = {"blur": BLUR_OF_CLOSURE, "render": RENDER_OF_CLOSURE, "two": TWO_CLOSURES, "timed_arg": TIMED_ARG}[name]
+    src = {"blur": BLUR_OF_CLOSURE, "render": RENDER_OF_CLOSURE, "two": TWO_CLOSURES, "timed_arg": TIMED_ARG,
+           "conditional_else": CONDITIONAL % 1, "conditional_then": CONDITIONAL % 2}[name]
     w, h = 192, 128
     img = np.ascontiguousarray(F.synthetic_image(w, h, seed=3))
     flt, inv = make_invocation(src, w, h, {}, {"in": img})

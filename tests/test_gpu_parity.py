@@ -399,6 +399,12 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
                                             got.ctypes.data_as(C.c_void_p))
     assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
     assert np.array_equal(got, want)
+    # ... and, directly, as the oracle (the two tiers share the engine below the importer: a lowering bug common to both
+    # would pass the comparison above)
+    tables = {"tone": F.test_curve(), "colors": F.test_gradient()} if name == "curve_gradient" else {}
+    oracle = CpuFilter(flt.ir_json_raw).render(w, h, uservals=tables, images={"in": marlene} if needs else {}, t=0.25)
+    mx, nd, n1 = stats(got, oracle)
+    EXP_ORACLE.check("abi/%s/256x256" % name, mx, nd, n1, got.size, default=(1, 0))
 
 
 def test_reference_abi_tier_specialises_from_the_second_frame(marlene):
