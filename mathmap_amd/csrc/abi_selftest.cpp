@@ -288,6 +288,9 @@ extern "C" {
 
 const char *mmhip_selftest_error(void) { return g_selftest_err.c_str(); }
 
+// the host's error buffer: the backend reports through it like the reference's backends do (exprtree.c:40, cc.c:653-693)
+char error_string[1024];
+
 // Compiles `source` with our front-end, exports the (un-optimised) IR into reference-layout
 // structures, pushes it through gen_and_load_hip_code and renders a w x h frame through the
 // returned mathfuncs into `out_rgba` (w*h*4 bytes).  Returns 0 on success.
@@ -382,7 +385,7 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
         g_img = image; g_iw = iw; g_ih = ih; g_ic = ichannels;
         mathmap_hip_set_get_pixel(selftest_get_pixel);
         mathmap.initfunc = gen_and_load_hip_code(&mathmap, &mathmap.module_info, nullptr, nullptr, codes.data());
-        if (!mathmap.initfunc) { g_selftest_err = std::string("gen_and_load_hip_code failed: ") + mmhip_last_error(); return -1; }
+        if (!mathmap.initfunc) { g_selftest_err = std::string("gen_and_load_hip_code failed: ") + error_string + mmhip_last_error(); return -1; }
 
         // invoke_mathmap defaults (mathmap_common.c:746-795)
         mmabi_invocation_t inv;

@@ -72,9 +72,7 @@ static void generate_closure_kernels(mmhip_filter *f, const KernelOptions &ko) {
     f->closures.clear();
     for (auto &sub : f->code->closure_renders) {
         mmhip_closure_kernel ck;
-        ck.ks = generate_hip(*sub, ko, f->code.get());
-        if (!ck.ks.natives.empty())
-            throw CompileError("a filter closure that is rendered for a native filter calls native filters itself: not supported");
+        ck.ks = generate_hip(*sub, ko, f->code.get());     // may call native filters itself: render_closure runs them first
         f->closures.push_back(std::move(ck));
     }
 }
@@ -353,6 +351,16 @@ mmhip_invocation *mmhip_invoke(mmhip_filter *f, int img_width, int img_height) {
         inv->images.push_back(d);
     }
     inv->closure_state.resize(f->closures.size());
+    for (size_t c = 0; c < f->closures.size(); ++c) {      // the closure kernels' own native-filter results: slots of their own
+        auto &st = inv->closure_state[c];
+        st.native_slot_base = (int)inv->images.size();
+        st.native_maps.assign(f->closures[c].ks.natives.size(), nullptr);
+        for (size_t k = 0; k < f->closures[c].ks.natives.size(); ++k) {
+            HImageDesc d{};
+            d.kind = IMG_NULL;
+            inv->images.push_back(d);
+        }
+    }
     inv->native_maps.assign(f->ks.natives.size(), nullptr);
     inv->native_map_size.assign(f->ks.natives.size(), {0, 0});
     inv->native_gen.assign(f->ks.natives.size(), 0);
@@ -391,6 +399,7 @@ void mmhip_invocation_free(mmhip_invocation *inv) {
         if (c.d_xy) (void)hipFree(c.d_xy);
         if (c.d_xtab) (void)hipFree(c.d_xtab);
         if (c.d_ytab) (void)hipFree(c.d_ytab);
+        for (void *p : c.native_maps) if (p) (void)hipFree(p);
     }
     inv->ws.release();
     if (inv->d_uv) (void)hipFree(inv->d_uv);
@@ -653,7 +662,12 @@ static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const
     mmhip_closure_kernel &ck = f->closures[cid];
     auto &st = inv->closure_state[cid];
     const int w = main_args.render_width, h = main_args.render_height;
-    if (st.map && (st.w != w || st.h != h)) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(st.map); st.map = nullptr; }
+    if (st.map && (st.w != w || st.h != h)) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(st.map);
+        st.map = nullptr;
+        for (void *&p : st.native_maps) { if (p) (void)hipFree(p); p = nullptr; }
+    }
     if (!st.map) { HIP_TRY(hipMalloc(&st.map, (size_t)w * h * 16)); st.w = w; st.h = h; }
     if (w > st.xtab_cap) {
         if (st.d_xtab) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(st.d_xtab); }
@@ -694,7 +708,46 @@ static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const
     char *xy = st.d_xy;
     void *params[] = {&a, &xy};
     const int n = std::max(w, h);
+    a.native_slot_base = st.native_slot_base;
     HIP_TRY(hipModuleLaunchKernel(ck.f_pro, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
+    if (!ck.ks.natives.empty()) {
+        // The closure's own calc_lines starts with its init_frame, and that is where *its* native filters run
+        // (builtins.c:273-298 -> new_template.c.in:314-337): the records its prologue just wrote, each executed call into a
+        // map of the closure's own.  Like the closure image itself these are recomputed on every render (the reference
+        // gives the closure a fresh id: nothing of it is ever found in the cache).
+        std::vector<char> host(ck.ks.xy_bytes);
+        HIP_TRY(hipMemcpyAsync(host.data(), st.d_xy, host.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (size_t k = 0; k < ck.ks.natives.size(); ++k) {
+            HNativeRec rec;
+            memcpy(&rec, host.data() + ck.ks.natives[k].record_offset, sizeof rec);
+            if (!rec.executed) continue;
+            for (int i = 0; i < rec.nargs && i < 4; ++i)
+                if (rec.args[i].kind == 2 && rec.args[i].img.idx <= -2)
+                    return fail("a filter closure rendered for a native filter hands another closure to a native filter: not supported");
+            if (!st.native_maps[k]) HIP_TRY(hipMalloc(&st.native_maps[k], (size_t)w * h * 16));
+            inv->ws.env.supersampling = f->kopt.supersampling;
+            inv->ws.env.edge_x = f->kopt.edge_x;
+            inv->ws.env.edge_y = f->kopt.edge_y;
+            inv->ws.env.edge_color_x = inv->edge_color_x;
+            inv->ws.env.edge_color_y = inv->edge_color_y;
+            std::string err;
+            int lo = 0, hi = h;
+            if (run_native_filter(ck.ks.natives[k].func, rec, inv->images, w, h, (float *)st.native_maps[k], inv->ws, s, &err, &lo, &hi) != 0)
+                return fail(err);
+            HImageDesc &d = inv->images[st.native_slot_base + (int)k];
+            d.data = st.native_maps[k];
+            d.w = w;
+            d.h = h;
+            d.kind = IMG_FLOATMAP;
+            d.num_frames = 1;
+            d.ax = d.bx = (float)((float)(d.w - 1) / 2.0);     // floatmap.c:39-41
+            d.ay = d.by = (float)((float)(d.h - 1) / 2.0);
+            d.ay *= -1.0f;
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(inv->d_images, inv->images.data(), inv->images.size() * sizeof(HImageDesc), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipModuleLaunchKernel(ck.f_pix, (unsigned)((long)tiles_x * tiles_y), 1, 1, 256, 1, 1, 0, s, params, nullptr));
     return 0;
 }

@@ -78,7 +78,8 @@ struct mmhip_invocation {
     unsigned long long native_gen_counter = 0;
     // closure images rendered for native filters: float map + the sub-launch's own constant buffer / tables
     struct ClosureState { void *map = nullptr; int w = 0, h = 0; char *d_xy = nullptr; int xy_cap = 0;
-                          float *d_xtab = nullptr, *d_ytab = nullptr; int xtab_cap = 0, ytab_cap = 0; };
+                          float *d_xtab = nullptr, *d_ytab = nullptr; int xtab_cap = 0, ytab_cap = 0;
+                          int native_slot_base = 0; std::vector<void *> native_maps; };   // native filters the closure's own code calls
     std::vector<ClosureState> closure_state;
     void *ss_lines = nullptr;              // the two slices of a supersampled render (own allocation:
     size_t ss_bytes = 0;                   // native filters reallocate `ws` underneath a nested render)

@@ -688,3 +688,19 @@ def test_pair_mode_engages_for_arithmetic_filters(monkeypatch):
     assert marker not in F.load("pond").kernel_source and marker not in F.load("ident").kernel_source
     monkeypatch.setenv("MMHIP_PAIR", "0")
     assert marker not in F.load("mandelbrot").kernel_source
+
+
+def test_reference_abi_tier_says_what_it_does_not_take():
+    """The backend reports through the host's error_string like the reference's backends (cc.c:653-693).  One case the
+    standalone tier renders and this tier still refuses: a closure image for a native filter whose own body calls a native
+    filter -- here the closure's body is a *called* filter function (filter_$name), and a native filter inside a function
+    would run per pixel."""
+    import ctypes as C
+    from mathmap_amd._lib import selftest_lib
+    from tests.test_gpu_closures import BLUR_OF_BLURRING_CLOSURE
+    img = np.ascontiguousarray(F.synthetic_image(64, 48, seed=3))
+    got = np.zeros((48, 64, 4), np.uint8)
+    rc = selftest_lib().mmhip_selftest_abi_roundtrip(BLUR_OF_BLURRING_CLOSURE.encode(), 1, img.ctypes.data_as(C.c_void_p), 64, 48, 3,
+                                                     64, 48, 0.25, 2, got.ctypes.data_as(C.c_void_p))
+    msg = selftest_lib().mmhip_selftest_error().decode()
+    assert rc != 0 and "gaussian_blur" in msg and "frame-constant" in msg, msg

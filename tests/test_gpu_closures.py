@@ -95,6 +95,37 @@ def test_closure_handed_to_a_native_filter_inside_a_conditional():
         assert np.array_equal(si.render(t=0.25), got), mode
 
 
+# a closure whose own body calls a native filter: the closure's calc_lines runs its init_frame first, and that is
+# where its gaussian_blur happens (builtins.c:273-298, new_template.c.in:314-337)
+BLUR_OF_BLURRING_CLOSURE = """
+filter soft (image in, float s: 0-1 (0.02), float k: 0-2 (0.8))
+  b = gaussian_blur(in, s, s * 2);
+  b(xy * k) * 0.9
+end
+
+filter outer (image in, float s: 0-1 (0.03))
+  c = gaussian_blur(soft(in, s * 0.5, 0.8 + t * 0.1), s, s);
+  c(xy)
+end
+"""
+
+
+def test_closure_that_calls_a_native_filter_itself():
+    w, h = 160, 96
+    img = F.synthetic_image(w, h, seed=3)
+    flt, inv = make_invocation(BLUR_OF_BLURRING_CLOSURE, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for t, s in ((0.25, 0.03), (0.8, 0.05), (0.25, 0.03)):
+        inv.set("s", s)
+        got = inv.render(t=t)
+        want = cf.render(w, h, uservals={"s": s}, images={"in": img}, t=t)
+        assert np.array_equal(got, want), (t, s, stats(got, want))
+    # float-map output of the same (no byte quantisation in between)
+    gm = render_device(inv, w, h, floatmap=True, t=0.25)
+    wm = cf.render(w, h, uservals={"s": 0.03}, images={"in": img}, t=0.25, floatmap=True)
+    assert np.array_equal(gm, wm)
+
+
 @pytest.mark.parametrize("name,src,tol", [("blur", BLUR_OF_CLOSURE, 0), ("render", RENDER_OF_CLOSURE, 0),
                                           ("two", TWO_CLOSURES, 0)])
 def test_native_filter_on_closure_image(name, src, tol):
