@@ -1076,11 +1076,13 @@ struct Generator {
             // 2-3 times longer than its top and bottom rows, Droste's level loop runs for some regions only, and the XCDs
             // that own the cheap bands idle while the others finish (first seen as two processes sharing the GPU rendering
             // 20 % more frames than one: the idle XCDs took the other process's workgroups).  Tiles in dispatch order (0)
-            // spread every region over all XCDs.  A/B at 8192^2 (tools/ab_xcd_order.sh, profiles/r03_ab_xcd_order.txt):
-            // Mandelbrot 0.265 -> 0.210 ms, Droste 1.226 -> 0.864 (NoTransparency=1: 0.909 -> 0.853), Pond 0.552 = 0.552,
-            // Ident 0.134 -> 0.139: only a body that is little more than its fetch (uniform work, the streaming shape of
-            // auto_tile_w) keeps the bands.
-            int xo = fetches >= 1 && stmts <= 12;
+            // spread every region over all XCDs but put horizontal neighbours on different L2s (Pond fetched 2.8x its
+            // input).  The default (2) deals runs of about one tile row to the XCDs in turn: balanced like (0), and a row's
+            // tiles share an L2 like in (1).  A/B at 8192^2, ms for orders 0 / 1 / 2 (tools/ab_xcd_order.sh,
+            // profiles/r03_ab_xcd_order.txt): Mandelbrot 0.209 / 0.263 / 0.201, Droste 0.860 / 1.217 / 0.855 (NoTransparency=1:
+            // 0.853 / 0.905 / 0.852), Pond 0.569 / 0.567 / 0.556, Ident 0.140 / 0.133 / 0.133.
+            int xo = 2;
+            (void)stmts;
             if (const char *e = getenv("MMHIP_XCD_ORDER")) xo = atoi(e);
             out << "#define MM_XCD_ORDER " << xo << "\n";
         }
@@ -1179,10 +1181,17 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
   const int tiles_x = (A.region_width + MM_TILE_W - 1) / MM_TILE_W;
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
-#if MM_XCD_ORDER
+#if MM_XCD_ORDER == 1
   const int xcd = bid & 7, q = bid >> 3;
   const int per = nwg >> 3, rem = nwg & 7;
   const int swz = xcd * per + (xcd < rem ? xcd : rem) + q;
+#elif MM_XCD_ORDER == 2
+  // runs of C = 2^m consecutive tiles (m: one tile row or a little more) dealt to the XCDs in turn: neighbours in a row
+  // share an L2 like in a band, and every XCD gets runs from all over the frame; the last partial round keeps dispatch order
+  const int m = 32 - __builtin_clz((unsigned)(tiles_x > 1 ? tiles_x - 1 : 1));
+  const int full = (nwg >> (m + 3)) << (m + 3);
+  const int q = bid >> 3;
+  const int swz = bid < full ? ((((q >> m) << 3) + (bid & 7)) << m) + (q & ((1 << m) - 1)) : bid;
 #else
   const int swz = bid;
   (void)nwg;
