@@ -42,7 +42,7 @@ namespace mm {
 
 namespace {
 
-enum Slice { PROLOGUE, PIXEL };
+enum Slice { PROLOGUE, PIXEL, ROWS };
 
 struct Generator {
     FilterCode &code;
@@ -140,6 +140,7 @@ struct Generator {
     bool value_visible(const Value *v, Slice sl) const {
         if (v->index < 0) return true;
         if (sl == PROLOGUE) return v->hoisted;
+        if (sl == ROWS) return v->row_const || transfer_off.count(const_cast<Value *>(v)) > 0;
         return !v->hoisted || transfer_off.count(const_cast<Value *>(v)) > 0;
     }
 
@@ -305,7 +306,7 @@ struct Generator {
                 if (p.kind == Primary::Val) uses.insert(p.value);
         };
         for (Stmt *s : b) {
-            bool mine = sl == PROLOGUE ? s->hoisted : s->in_pixel;
+            bool mine = sl == PROLOGUE ? s->hoisted : sl == ROWS ? s->in_row : s->in_pixel;
             if (!mine) continue;
             switch (s->kind) {
                 case Stmt::Assign: defs.push_back(s->lhs); use(s->rhs); break;
@@ -929,7 +930,7 @@ struct Generator {
     void stmts(Block &b, Slice sl, const std::string &ind) {
         if (opt.fast_math_exact && sl == PIXEL && sincos_scanned.insert(&b).second) pair_sincos(b, sl);
         for (Stmt *s : b) {
-            bool mine = sl == PROLOGUE ? s->hoisted : s->in_pixel;
+            bool mine = sl == PROLOGUE ? s->hoisted : sl == ROWS ? s->in_row : s->in_pixel;
             if (!mine) continue;
             switch (s->kind) {
                 case Stmt::Assign: {
@@ -1024,13 +1025,120 @@ struct Generator {
         return it == native_index.end() ? -1 : it->second;
     }
 
+    // ---- the per-row slice ------------------------------------------------------------------
+    // The reference evaluates code that depends on y alone once per row (its "x-const" slice, new_template.c.in:251-253,
+    // compiler.c:4550-4611).  Here: top-level assignments of the pixel slice whose operands are literals, frame constants,
+    // the row coordinate or other such values form the row slice -- when it contains a library call (everything else is
+    // cheaper to recompute per pixel than to load) -- and a kernel of its own, mm_rows, evaluates it once per row of the
+    // launch; the pixel kernel reads the values it needs from mm_args.rowtab like it reads y from ytab.
+    std::vector<Value *> row_transfer;        // row values the pixel slice uses, in table order
+    static bool row_scalar(Ty t) { return t == Ty::Int || t == Ty::Float || t == Ty::Complex; }
+    static bool row_expensive(const char *cn) {
+        static const char *cheap[] = {"fabs", "floor", "ceil", "crealf", "cimagf"};
+        for (const char *c : cheap) if (!strcmp(cn, c)) return false;
+        return std::islower((unsigned char)cn[0]) || !strncmp(cn, "ELL_", 4) || !strcmp(cn, "GAMMA");
+    }
+    void uses_of_pixel_code(const Block &b, std::set<const Value *> &used) const {
+        auto use = [&](const Rhs &r) {
+            if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val) used.insert(r.prim.value);
+            for (const Primary &p : r.args) if (p.kind == Primary::Val) used.insert(p.value);
+        };
+        for (const Stmt *s : b) {
+            if (!s->in_pixel) continue;
+            switch (s->kind) {
+                case Stmt::Assign: use(s->rhs); break;
+                case Stmt::Phi: use(s->rhs); use(s->rhs2); break;
+                case Stmt::If: use(s->cond); uses_of_pixel_code(s->then_, used); uses_of_pixel_code(s->else_, used); uses_of_pixel_code(s->phis, used); break;
+                case Stmt::While: uses_of_pixel_code(s->phis, used); use(s->cond); uses_of_pixel_code(s->body, used); break;
+                default: break;
+            }
+        }
+    }
+    void find_row_slice() {
+        if (fn_root || in_function || getenv("MMHIP_NO_ROW_SLICE")) return;
+        std::vector<Stmt *> cand;
+        std::set<const Value *> rows;
+        auto operand_ok = [&](const Primary &p) {
+            return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted || rows.count(p.value) > 0;
+        };
+        for (Stmt *s : code.body) {           // top level only: no control flow in the row slice
+            if (s->kind != Stmt::Assign || !s->in_pixel || s->hoisted || !row_scalar(s->lhs->var->type)) continue;
+            const Rhs &r = s->rhs;
+            bool ok = false;
+            if (r.kind == Rhs::Internal) ok = r.internal == "y";
+            else if (r.kind == Rhs::Prim) ok = operand_ok(r.prim) && r.prim.kind == Primary::Val && rows.count(r.prim.value);
+            else if (r.kind == Rhs::Op && r.op->pure) {
+                ok = true;
+                bool any_row = false;
+                for (const Primary &p : r.args) {
+                    ok = ok && operand_ok(p) && (p.kind != Primary::Val || p.value->index < 0 || row_scalar(p.value->var->type));
+                    any_row = any_row || (p.kind == Primary::Val && rows.count(p.value));
+                }
+                ok = ok && any_row && strncmp(r.op->cname, "USERVAL_", 8) != 0;
+            }
+            if (!ok) continue;
+            cand.push_back(s);
+            rows.insert(s->lhs);
+        }
+        // what the pixel code reads must travel as a 32-bit word: a complex row value that is used per pixel goes back to
+        // the pixel slice, and with it whatever was computed from it
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (Stmt *s : cand) s->in_pixel = !rows.count(s->lhs);
+            std::set<const Value *> used;
+            uses_of_pixel_code(code.body, used);
+            for (int i = 0; i < 4; ++i) used.insert(code.result[i]);
+            for (Stmt *s : cand) {
+                if (!rows.count(s->lhs)) continue;
+                bool drop = used.count(s->lhs) && s->lhs->var->type == Ty::Complex;
+                if (s->rhs.kind == Rhs::Prim) drop = drop || !rows.count(s->rhs.prim.value);
+                for (const Primary &p : s->rhs.args)
+                    drop = drop || (p.kind == Primary::Val && p.value->index >= 0 && !p.value->hoisted && !rows.count(p.value));
+                if (drop) { rows.erase(s->lhs); changed = true; }
+            }
+        }
+        bool expensive = false;
+        for (Stmt *s : cand)
+            expensive = expensive || (rows.count(s->lhs) && s->rhs.kind == Rhs::Op && row_expensive(s->rhs.op->cname));
+        std::set<const Value *> used;
+        for (Stmt *s : cand) s->in_pixel = !rows.count(s->lhs);
+        uses_of_pixel_code(code.body, used);
+        for (int i = 0; i < 4; ++i) used.insert(code.result[i]);
+        std::vector<Value *> transfer;
+        for (Stmt *s : cand) if (rows.count(s->lhs) && used.count(s->lhs)) transfer.push_back(s->lhs);
+        if (!expensive || transfer.empty() || transfer.size() > 24) {
+            for (Stmt *s : cand) s->in_pixel = true;
+            return;
+        }
+        for (Stmt *s : cand)
+            if (rows.count(s->lhs)) { s->in_row = true; s->in_pixel = false; s->lhs->row_const = true; }
+        row_transfer = transfer;
+        ks.row_values = (int)transfer.size();
+        ks.rows_name = "mm_rows";
+    }
+    // the row values a pixel of row `row` needs, from the table mm_rows filled
+    void row_loads(const std::string &ind, const char *row) {
+        for (size_t k = 0; k < row_transfer.size(); ++k) {
+            Value *v = row_transfer[k];
+            const std::string at = "A.rowtab[" + std::to_string(k) + " * A.num_rows + " + row + "]";
+            out << ind << "const " << ctype(v->var) << " " << vname(v) << " = "
+                << (v->var->type == Ty::Int ? "__float_as_int(" + at + ")" : at) << ";\n";
+        }
+    }
+
     void analyze_and_layout() {
         find_natives(code.body);
         ks.direct_native = find_direct_native();
+        find_row_slice();
+        std::vector<Value *> row_defs;
+        std::set<Value *> row_uses;
         collect_values(code.body, PROLOGUE, pro_defs, pro_uses);
         collect_values(code.body, PIXEL, pix_defs, pix_uses);
+        collect_values(code.body, ROWS, row_defs, row_uses);
+        for (Value *v : row_uses) if (v && v->hoisted) pix_uses.insert(v);      // frame constants the row slice reads travel in XY too
         for (int i = 0; i < 4; ++i) pix_uses.insert(code.result[i]);
         std::set<Value *> pix_def_set(pix_defs.begin(), pix_defs.end());
+        for (Value *v : row_transfer) pix_def_set.insert(v);                    // defined (loaded) per pixel
         int off = 0;
         // native call records first (fixed layout the host can parse)
         for (NativeCall &nc : ks.natives) {
@@ -1094,7 +1202,7 @@ struct Generator {
         out << "#define MM_EDGE_X " << opt.edge_x << "\n#define MM_EDGE_Y " << opt.edge_y << "\n";
         out << "#define MM_TILE_W " << ks.tile_w << "\n#define MM_TILE_H " << ks.tile_h << "\n";
         ks.unroll = opt.unroll > 0 ? opt.unroll : auto_unroll();
-        pair_mode = opt.unroll <= 0 && !getenv("MMHIP_UNROLL") && pair_eligible();
+        pair_mode = opt.unroll <= 0 && !getenv("MMHIP_UNROLL") && ks.row_values == 0 && pair_eligible();   // (row values are per pixel of a pair)
         if (pair_mode) { ks.unroll = 2; pair_infer_bools(); }
         out << "#define MM_UNROLL " << ks.unroll << "\n";
         // float-argument sin/cos (mm_fastmath.h), the same text the host verifier compiles; it
@@ -1170,6 +1278,29 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
         for (Value *v : transfer_order)
             out << "  *(" << ctype(v->var) << " *)(XY + " << transfer_off[v] << ") = " << vname(v) << ";\n";
         out << "}\n\n";
+        // ---- rows kernel: the per-row slice, one lane per row of the launch ----
+        if (ks.row_values > 0) {
+            out << "extern \"C\" __global__ void __launch_bounds__(256) mm_rows(mm_args A, const char *__restrict__ XY) {\n"
+                   "  const int rl = blockIdx.x * 256 + threadIdx.x;\n"
+                   "  if (rl >= A.num_rows) return;\n"
+                   "  MM_INTERNALS\n"
+                   "  const float y = A.ytab[rl];    // CALC_VIRTUAL_Y(first_row + rl, ...), by the prologue\n"
+                   "  (void)y;\n";
+            std::vector<Value *> rdefs;
+            std::set<Value *> ruses;
+            collect_values(code.body, ROWS, rdefs, ruses);
+            for (Value *v : transfer_order)
+                if (ruses.count(v))
+                    out << "  const " << ctype(v->var) << " " << vname(v) << " = *(const " << ctype(v->var) << " *)(XY + " << transfer_off[v] << ");\n";
+            decls(rdefs, "  ");
+            stmts(code.body, ROWS, "  ");
+            for (size_t k = 0; k < row_transfer.size(); ++k) {
+                Value *v = row_transfer[k];
+                out << "  A.rowtab[" << k << " * A.num_rows + rl] = "
+                    << (v->var->type == Ty::Int ? "__int_as_float(" + vname(v) + ")" : vname(v)) << ";\n";
+            }
+            out << "}\n\n";
+        }
         // ---- pixel kernel ----
         // experiment hook: ask the register allocator for a minimum occupancy (waves per SIMD)
         if (const char *e = getenv("MMHIP_WAVES_PER_EU")) out << "__attribute__((amdgpu_waves_per_eu(" << atoi(e) << "))) ";
@@ -1226,6 +1357,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                    "  const float y = A.ytab[rl];    // CALC_VIRTUAL_Y(first_row + rl, ...), once per row by the prologue\n"
                    "  unsigned mm_rand_ctr = 0;      // RAND call number within this pixel\n"
                    "  (void)y; (void)mm_rand_ctr;\n";
+            row_loads("  ", "rl");
             decls(pix_defs, "  ");
             stmts(code.body, PIXEL, "  ");
             out << "  mm_tup<4> rt;\n";
@@ -1289,6 +1421,7 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                 << I << "    const int rl = rl_u < A.num_rows ? rl_u : A.num_rows - 1;\n"
                 << I << "    unsigned mm_rand_ctr = 0;      // RAND call number within this pixel\n"
                 << I << "    (void)y; (void)rl; (void)mm_rand_ctr;\n";
+            row_loads(I + "    ", "rl");
             decls(pix_defs, (I + "    ").c_str());
             stmts(code.body, PIXEL, (I + "    ").c_str());
             for (int i = 0; i < 4 && !fetched; ++i)

@@ -37,6 +37,8 @@ struct KernelSource {
     int unroll = 1;               // MM_UNROLL of the pixel kernel; the launch's rows per work-item is a multiple
     bool prologue_uses_time = true;   // frame-constant code reads t or frame: re-run it for every frame
     bool single_pixel = false;    // kernel renders exactly one pixel per work-item: launch with ppt = 1
+    int row_values = 0;           // > 0: kernel `mm_rows` fills that many per-row values (mm_args.rowtab) before the pixel kernel
+    std::string rows_name;
     int direct_native = -1;       // index into natives: the pixel is that result sampled at (x, y) and nothing else
     std::string key;              // cache key (hash of source)
 };

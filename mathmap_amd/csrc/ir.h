@@ -70,6 +70,7 @@ struct Value {
     Stmt *def = nullptr;
     unsigned constness = CONST_MAX;
     bool hoisted = false;  // lives in the frame-constant block
+    bool row_const = false;   // depends on the row alone: computed once per row by the rows kernel (hipgen.cpp find_row_slice)
 };
 
 struct Primary {
@@ -115,6 +116,7 @@ struct Stmt {
     Stmt *parent = nullptr;
     bool hoisted = false;     // belongs (also) to the frame-constant slice
     bool in_pixel = true;     // belongs (also) to the per-pixel slice
+    bool in_row = false;      // belongs to the per-row slice (the reference's x-const code, new_template.c.in:251-253)
     // Assign of a MathMap closure that a native filter (or render()) takes as an image: index into
     // FilterCode::closure_renders, the code that renders it into a float map (render_image's closure
     // branch, builtins.c:267-302); -1 otherwise

@@ -89,6 +89,9 @@ struct mm_args {
     float *ytab;
     unsigned tiles_magic;             // workgroup id / tile columns by multiply-high (mm_host_abi.h), 0: divide
     unsigned pad_;
+    // values that depend on the row alone (the reference's x-const slice, new_template.c.in:251-253), computed once per
+    // row of the launch by mm_rows: value k of row r at rowtab[k * num_rows + r] (ints stored as their bit pattern)
+    float *rowtab;
 };
 
 // ---- op macros (opmacros.h:30-47) --------------------------------------------------

@@ -47,6 +47,7 @@ struct HArgs {
     float *ytab;
     uint32_t tiles_magic;     // ceil(2^32 / tiles_x) when workgroup id / tiles_x is exact by multiply-high, else 0
     uint32_t pad_;
+    float *rowtab;            // per-row values of the launch (mm_rows), [value][row]
 };
 
 // workgroup id -> (tile row, tile column) is one division by the number of tile columns per work-item start-up; a
@@ -63,6 +64,6 @@ struct HNativeRec { int executed; int index; int nargs; int pad; HNativeArg args
 static_assert(sizeof(HImage) == 24, "mm_image layout");
 static_assert(sizeof(HImageDesc) == 56, "mm_image_desc layout");
 static_assert(sizeof(HNativeArg) == 36, "mm_narg_t layout");
-static_assert(sizeof(HArgs) == 160, "mm_args layout");
+static_assert(sizeof(HArgs) == 168, "mm_args layout");
 
 }  // namespace mm

@@ -287,6 +287,10 @@ long mmhip_filter_jit(mmhip_filter *f, int load_module) {
         if (jit_source(ck.ks, ck.code_object) != 0) return -1;
     if (load_module && !f->loaded) {
         if (load_kernels(f->ks, f->code_object, &f->mod, &f->f_pix, &f->f_pro) != 0) return -1;
+        if (f->ks.row_values > 0) {
+            hipError_t e = hipModuleGetFunction(&f->f_rows, f->mod, f->ks.rows_name.c_str());
+            if (e != hipSuccess) return fail(std::string("hipModuleGetFunction(rows): ") + hipGetErrorString(e));
+        }
         for (mmhip_closure_kernel &ck : f->closures)
             if (!ck.loaded) {
                 if (load_kernels(ck.ks, ck.code_object, &ck.mod, &ck.f_pix, &ck.f_pro) != 0) return -1;
@@ -407,6 +411,7 @@ void mmhip_invocation_free(mmhip_invocation *inv) {
     if (inv->d_xy) (void)hipFree(inv->d_xy);
     if (inv->d_xtab) (void)hipFree(inv->d_xtab);
     if (inv->d_ytab) (void)hipFree(inv->d_ytab);
+    if (inv->d_rowtab) (void)hipFree(inv->d_rowtab);
     if (inv->d_curves) (void)hipFree(inv->d_curves);
     if (inv->d_gradients) (void)hipFree(inv->d_gradients);
     for (auto &p : inv->ev_pool) {
@@ -1060,6 +1065,18 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     }
     a.xtab = inv->d_xtab;
     a.ytab = inv->d_ytab;
+    if (f->ks.row_values > 0) {
+        const size_t need = (size_t)f->ks.row_values * (size_t)a.num_rows;
+        if (need > inv->rowtab_cap) {
+            if (inv->d_rowtab) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(inv->d_rowtab); }
+            inv->d_rowtab = nullptr;
+            inv->rowtab_cap = 0;
+            HIP_TRY(hipMalloc((void **)&inv->d_rowtab, need * sizeof(float)));
+            inv->rowtab_cap = need;
+            inv->pro_filter = nullptr;           // the table is new: fill it
+        }
+        a.rowtab = inv->d_rowtab;
+    }
 
     if (f->ks.xy_bytes > inv->xy_cap) {
         if (inv->d_xy) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(inv->d_xy); }
@@ -1086,6 +1103,9 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
         if (!fresh) {
             int n = std::max(region_w, a.num_rows);
             HIP_TRY(hipModuleLaunchKernel(f->f_pro, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
+            // the per-row slice (x-const code): once per row of the launch, after the frame constants it reads
+            if (f->ks.row_values > 0)
+                HIP_TRY(hipModuleLaunchKernel(f->f_rows, (unsigned)((a.num_rows + 255) / 256), 1, 1, 256, 1, 1, 0, s, params, nullptr));
             if (!f->ks.natives.empty() && run_natives(inv, f, a, s, &direct_written) != 0) return -1;
             inv->pro_args = key;
             inv->pro_filter = f;

@@ -38,6 +38,7 @@ struct mmhip_filter {
     std::vector<char> code_object;
     hipModule_t mod = nullptr;
     hipFunction_t f_pro = nullptr, f_pix = nullptr;
+    hipFunction_t f_rows = nullptr;           // the per-row slice's kernel (KernelSource::row_values > 0)
     bool loaded = false;
     double jit_seconds = 0;
     // user-value specialisation (specialize.cpp): kernels with the scalar user values baked in,
@@ -100,6 +101,8 @@ struct mmhip_invocation {
     int xy_cap = 0;
     float *d_xtab = nullptr, *d_ytab = nullptr;   // per-column / per-row coordinates of the current launch
     int xtab_cap = 0, ytab_cap = 0;
+    float *d_rowtab = nullptr;                    // per-row values of the current launch (mm_rows): [value][row]
+    size_t rowtab_cap = 0;
     hipStream_t stream = nullptr;
     uint32_t edge_color_x = 0, edge_color_y = 0;
     float sampling_offset_x = 0.f, sampling_offset_y = 0.f;

@@ -483,6 +483,50 @@ def test_real_math_float_ulps(expr, label, max_ulp):
     assert (ulps == 0).mean() > (0.98 if "beyond" in label else 0.999), "%s: only %.5f identical" % (label, (ulps == 0).mean())
 
 
+ROW_SLICE_FILTERS = [
+    # a wave distortion: sin of the row coordinate (and t) is a per-row value
+    ("wave", "filter wave (image in, float amp: 0-1 (0.1)) in(xy + xy:[sin(y * 10 + t * 6) * amp, 0]) end", True),
+    # per-row and per-column library calls side by side (the per-column one stays in the pixel loop: hoisted by the compiler)
+    ("both", "filter both (image in) in(xy + xy:[sin(y * 10) * 0.1, cos(x * 7) * 0.05]) end", True),
+    # a complex per-row value: its real and imaginary parts travel, the complex value itself does not
+    ("cplx", "filter cplx () w = exp(ri:[0, y * 3]); grayColor(w[0] * x + w[1]) end", True),
+    # integer per-row values (floor) and a row value that is the result by itself
+    ("ints", "filter ints () k = floor(abs(sin(y * 9)) * 5); rgba:[k / 5, exp(y) / 3, x * k / 5, 1] end", True),
+    # nothing worth a table: plain arithmetic on y is recomputed per pixel
+    ("none", "filter none (image in) in(xy + xy:[y * 0.1, 0]) end", False),
+]
+
+
+@pytest.mark.parametrize("name,src,has_rows", ROW_SLICE_FILTERS, ids=[f[0] for f in ROW_SLICE_FILTERS])
+def test_per_row_slice_matches_oracle(name, src, has_rows, monkeypatch):
+    """The per-row (x-const) slice: values that depend on the row alone come from the rows kernel's table.  Whole frames,
+    row bands, a region with an offset, float-map output, and the same filter with the slice switched off."""
+    w, h = 333, 207
+    img = F.synthetic_image(w, h, seed=12)
+    flt = mm.Filter(src)
+    assert ("mm_rows(mm_args" in flt.kernel_source) == has_rows
+    needs = bool(F.image_names(flt))
+    images = {"in": img} if needs else {}
+    cf = CpuFilter(flt.ir_json_raw)
+    inv = flt.invoke(w, h)
+    if needs:
+        inv.set_image("in", img)
+    for t in (0.0, 0.37):
+        want = cf.render(w, h, images=images, t=t)
+        assert np.array_equal(inv.render(t=t), want), (name, t)
+        got = render_device(inv, w, h, rows=[(0, 50), (50, 51), (51, 207)], t=t)
+        assert np.array_equal(got, want), (name, "bands")
+    gm = render_device(inv, w, h, floatmap=True, t=0.37)
+    assert np.array_equal(gm, cf.render(w, h, images=images, t=0.37, floatmap=True))
+    monkeypatch.setenv("MMHIP_NO_ROW_SLICE", "1")
+    off = mm.Filter(src)
+    assert "mm_rows(mm_args" not in off.kernel_source
+    oi = off.invoke(w, h)
+    if needs:
+        oi.set_image("in", img)
+    assert np.array_equal(oi.render(t=0.37), want)
+
+
 def test_acos_asin_fast_forms_equal_the_verified_table_forms_for_every_float():
     """mm_fastmath.h: the kernels call the platform's double acos / asin and let its result decide the float unless it lies
     next to a rounding tie, where the table form -- compared with glibc for every float in [-1, 1] on the host
