@@ -93,7 +93,7 @@ SELFTEST_SYMBOLS = {
     "mmhip_selftest_abi_roundtrip": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "mmhip_selftest_error": (C.c_char_p, []),
-    "mmhip_selftest_acos_asin_exhaustive": (C.c_int, [C.POINTER(C.c_ulonglong)]),
+    "mmhip_selftest_eval_unary": (C.c_int, [C.c_int, C.c_uint, C.c_ulonglong, C.c_void_p]),
 }
 SELFTEST_PATH = os.path.join(os.path.dirname(_HERE), "tests", "libmathmap_hip_selftest.so")
 _selftest = None

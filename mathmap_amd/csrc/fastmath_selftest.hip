@@ -1,19 +1,14 @@
-// Device-side exhaustive check of the float-argument acos / asin (test scaffolding: linked into
-// tests/libmathmap_hip_selftest.so, not into the product library).
-//
-// mm_fastmath.h has two layers for these functions: the table forms (mmf_acos_f32, mmf_asin_f32), which the host verifier
-// compares with glibc for every float in [-1, 1], and the fast forms the kernels call (mmf_acos_fast_f32,
-// mmf_asin_fast_f32): the platform's double function, falling back to the table form next to a float rounding tie.  The
-// platform function on the device is OCML's, which no host run can exercise -- so the device enumerates every float in
-// [-1, 1] (and the first floats beyond) and counts where the two layers disagree.  0 means: on this GPU the fast forms
-// return glibc's (float)acos((double)x) / (float)asin((double)x) for every argument.
+// Device side of the every-float check of the real one-argument math ops (test scaffolding: linked into
+// tests/libmathmap_hip_selftest.so, not into the product library).  The kernel evaluates what a JIT kernel computes for
+// `op` of a float -- the functions hipgen.cpp names -- on runs of consecutive float bit patterns; the caller compares with
+// glibc's double function rounded to float (oracle/libm_ref.c, same op numbering).  No host run can exercise the platform's
+// (OCML's) functions, which most of these ops are; this does, for every argument.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstring>
 
 #define MMF_FN static __device__ __forceinline__
-#define MMF_COLD_FN static __device__ __attribute__((noinline))
 #define MMF_CONST_TABLE static __device__ const
 #define MMF_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define MMF_RINT(a) __builtin_rint((a))
@@ -25,47 +20,56 @@
 #define MMF_EXP_SLOW(a) exp((a))
 #define MMF_LOG_SLOW(a) log((a))
 #define MMF_POW_SLOW(a, b) pow((a), (b))
-#define MMF_ACOS_SLOW(a) acos((a))
-#define MMF_ASIN_SLOW(a) asin((a))
 #define MMF_SQRT(a) __builtin_sqrt((a))
 #define MMF_HYPOT_SLOW(a, b) hypot((a), (b))
+#define MMF_ASINH_SLOW(a) asinh((a))
+#define MMF_ACOSH_SLOW(a) acosh((a))
 #include "mm_fastmath.h"
 
+// ---- every real one-argument math op on a run of consecutive float bit patterns -------------------------------
+// What a kernel computes for `op` of a float (the functions hipgen.cpp names), for arguments first, first + 1, ...; the
+// caller compares with glibc (oracle/libm_ref.c, same op numbering).
 namespace {
+enum { OP_SIN, OP_COS, OP_TAN, OP_ASIN, OP_ACOS, OP_ATAN, OP_EXP, OP_LOG, OP_SINH, OP_COSH, OP_TANH, OP_ASINH, OP_ACOSH, OP_ATANH };
 
-struct Counts { unsigned long long checked, bad_acos, bad_asin, fallbacks; unsigned first_bad_acos, first_bad_asin; };
-
-__global__ void __launch_bounds__(256) k_check(Counts *out, unsigned limit_bits) {
-    unsigned long long bad_a = 0, bad_s = 0, n = 0, fb = 0;
-    for (unsigned long long u = (unsigned long long)blockIdx.x * 256 + threadIdx.x; u <= limit_bits; u += (unsigned long long)gridDim.x * 256)
-        for (unsigned sign = 0; sign < 2; ++sign) {
-            const unsigned bits = (unsigned)u | (sign << 31);
-            const float x = __uint_as_float(bits);
-            const float fa = mmf_acos_fast_f32(x), ta = mmf_acos_f32(x), fs = mmf_asin_fast_f32(x), ts = mmf_asin_f32(x);
-            const bool na = fa != fa && ta != ta, ns = fs != fs && ts != ts;         // NaN on both sides (|x| > 1)
-            if (__float_as_uint(fa) != __float_as_uint(ta) && !na) { if (!bad_a) atomicCAS(&out->first_bad_acos, 0u, bits); ++bad_a; }
-            if (__float_as_uint(fs) != __float_as_uint(ts) && !ns) { if (!bad_s) atomicCAS(&out->first_bad_asin, 0u, bits); ++bad_s; }
-            fb += mmf_near_float_tie(acos((double)x)) ? 1 : 0;
-            ++n;
-        }
-    atomicAdd(&out->checked, n);
-    if (bad_a) atomicAdd(&out->bad_acos, bad_a);
-    if (bad_s) atomicAdd(&out->bad_asin, bad_s);
-    if (fb) atomicAdd(&out->fallbacks, fb);
+__device__ __forceinline__ float eval_unary(int op, float x) {
+    switch (op) {
+        case OP_SIN: return mmf_sin_f32(x);                     // table-driven below 2^22, the platform's beyond
+        case OP_COS: return mmf_cos_f32(x);
+        case OP_EXP: return mmf_exp_f32(x);
+        case OP_LOG: return mmf_log_f32(x);
+        case OP_ASINH: return mmf_asinh_f32(x);                 // the platform's + exception list
+        case OP_ACOSH: return mmf_acosh_f32(x);
+        case OP_TAN: return (float)tan((double)x);              // the platform's double function, as mm_device.h calls it
+        case OP_ASIN: return (float)asin((double)x);
+        case OP_ACOS: return (float)acos((double)x);
+        case OP_ATAN: return (float)atan((double)x);
+        case OP_SINH: return (float)sinh((double)x);
+        case OP_COSH: return (float)cosh((double)x);
+        case OP_TANH: return (float)tanh((double)x);
+        case OP_ATANH: return (float)atanh((double)x);
+        default: return 0.0f;
+    }
 }
 
+__global__ void __launch_bounds__(256) k_eval_unary(int op, unsigned first, unsigned long long count, unsigned *out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256)
+        out[i] = __float_as_uint(eval_unary(op, __uint_as_float(first + (unsigned)i)));
+}
 }  // namespace
 
-// out[0..5] = values checked, acos mismatches, asin mismatches, arguments that took acos's fallback, first bad argument bits
-// (acos, asin).  Returns 0 when the kernel ran.
-extern "C" int mmhip_selftest_acos_asin_exhaustive(unsigned long long *out) {
-    Counts *d = nullptr, h;
-    if (hipMalloc((void **)&d, sizeof(Counts)) != hipSuccess) return -1;
-    if (hipMemset(d, 0, sizeof(Counts)) != hipSuccess) return -1;
-    k_check<<<256 * 64, 256>>>(d, 0x3f800010u);
+// Result bits of `op` for the `count` arguments whose bits are first, first + 1, ... into host memory.  Returns 0.
+extern "C" int mmhip_selftest_eval_unary(int op, unsigned first, unsigned long long count, unsigned *out_host) {
+    static unsigned *d = nullptr;
+    static unsigned long long cap = 0;
+    if (count > cap) {
+        if (d) (void)hipFree(d);
+        d = nullptr;
+        if (hipMalloc((void **)&d, count * sizeof(unsigned)) != hipSuccess) { cap = 0; return -1; }
+        cap = count;
+    }
+    k_eval_unary<<<4096, 256>>>(op, first, count, d);
     if (hipDeviceSynchronize() != hipSuccess) return -2;
-    if (hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -3;
-    (void)hipFree(d);
-    out[0] = h.checked; out[1] = h.bad_acos; out[2] = h.bad_asin; out[3] = h.fallbacks; out[4] = h.first_bad_acos; out[5] = h.first_bad_asin;
+    if (hipMemcpy(out_host, d, count * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -3;
     return 0;
 }

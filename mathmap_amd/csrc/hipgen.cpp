@@ -275,10 +275,10 @@ struct Generator {
                     else if (!strcmp(cn, "cos")) name = "mmf_cos_f32";
                     else if (!strcmp(cn, "exp")) name = "mmf_exp_f32";
                     else if (!strcmp(cn, "log")) name = "mmf_log_f32";
-                    // the platform's double function where its result decides the float, the table form (verified against
-                    // glibc for every float in [-1, 1]) next to a rounding tie; equal to glibc for every float on the device
-                    else if (!strcmp(cn, "acos")) name = "mmf_acos_fast_f32";
-                    else if (!strcmp(cn, "asin")) name = "mmf_asin_fast_f32";
+                    // the platform's double function and the list of the arguments where its float differs from glibc's
+                    // (mm_libm_exceptions.h; the other one-argument functions have no such argument: tools/libm_exceptions.py)
+                    else if (!strcmp(cn, "asinh")) name = "mmf_asinh_f32";
+                    else if (!strcmp(cn, "acosh")) name = "mmf_acosh_f32";
                 }
                 if (lhs && lhs->type == Ty::Int && (!strcmp(cn, "floor") || !strcmp(cn, "ceil")))
                     name = !strcmp(cn, "floor") ? "mm_floor_i" : "mm_ceil_i";      // x86 double -> int conversion
@@ -1208,14 +1208,13 @@ struct Generator {
         // float-argument sin/cos (mm_fastmath.h), the same text the host verifier compiles; it
         // precedes the device prelude, whose complex functions use mmf_sincos_d
         out << "#define MMF_FN static __device__ __forceinline__\n#define MMF_CONST_TABLE static __device__ const\n"
-               "#define MMF_COLD_FN static __device__ __attribute__((noinline))\n"
                "#define MMG_FN static __device__\n"
                "#define MMF_FMA(a, b, c) __builtin_fma((a), (b), (c))\n#define MMF_RINT(a) __builtin_rint((a))\n"
                "#define MMF_FABSF(a) __builtin_fabsf((a))\n#define MMF_FABS(a) __builtin_fabs((a))\n"
                "#define MMF_SIN_SLOW(a) sin((a))\n#define MMF_COS_SLOW(a) cos((a))\n"
                "#define MMF_LDEXP(a, e) __builtin_ldexp((a), (e))\n#define MMF_EXP_SLOW(a) exp((a))\n#define MMF_LOG_SLOW(a) log((a))\n"
                "#define MMF_POW_SLOW(a, b) pow((a), (b))\n"
-               "#define MMF_ACOS_SLOW(a) acos((a))\n#define MMF_ASIN_SLOW(a) asin((a))\n"
+               "#define MMF_ASINH_SLOW(a) asinh((a))\n#define MMF_ACOSH_SLOW(a) acosh((a))\n"
                "#define MMF_SQRT(a) __builtin_sqrt((a))\n#define MMF_HYPOT_SLOW(a, b) hypot((a), (b))\n"
                // mm_glibcf.h (glibc's float algorithms for the complex ops); float sqrt / division are the correctly
                // rounded device ones, double sqrt is the compiler's correctly rounded expansion

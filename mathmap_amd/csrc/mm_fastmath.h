@@ -284,132 +284,47 @@ MMF_FN float mmf_pow_f32(float x, float y) {
     return (float)r;
 }
 
-// ---- acos and asin of a float argument --------------------------------------------------------------------
-// (float)acos((double)x) and (float)asin((double)x) -- every filter in polar coordinates evaluates a = acos(x / r) per
-// pixel (compiler.c:2467-2511).  Two layers:
-//   * mmf_acos_f32 / mmf_asin_f32, "the table form": piecewise Taylor polynomials around tabulated centres in double
-//       u = |x| <= 1/2:           64 intervals of width 1/128, acos(u) = c0 + h P(h), h = u - c exact, degree 6;
-//       z = 1 - u in [2^-10,1/2): 32 intervals per binade of z (the function is sqrt(2z) times a smooth factor), centre
-//                                 from the bits of z, degree 7;
-//       z < 2^-10:                sqrt(2z) (1 + z/12 + 3z^2/160 + ...) with the square root's residual;
-//     the constant term of an interval is stored three times as a double-double -- acos(c), pi - acos(c) for negative
-//     arguments, pi/2 - acos(c) for asin -- so every result is one rounded sum hi + (lo +- h P(h)).
-//     tools/verify_fastmath.c compares both with glibc for EVERY float in [-1, 1]: 0 mismatches.  It is exact and slow
-//     on the GPU (a wave's lanes gather from up to 64 table rows: profiles/r03_acos_table_experiment.txt);
-//   * mmf_acos_fast_f32 / mmf_asin_fast_f32, what the kernels call: the platform's double function, whose result decides
-//     the float unless it lies within MMF_TIE_BAND double ulps of a float rounding tie (once in 2^25 calls) -- only then
-//     the table form is evaluated.  That the two layers agree on the device for every float in [-1, 1] is checked there,
-//     exhaustively (tests/test_gpu_parity.py::test_acos_asin_fast_forms_equal_the_verified_table_forms_for_every_float).
-#ifndef MMF_ACOS_SLOW
-#define MMF_ACOS_SLOW(a) acos((a))
-#define MMF_ASIN_SLOW(a) asin((a))
-#endif
-#ifndef MMF_SQRT
-#define MMF_SQRT(a) sqrt((a))
-#endif
-#ifndef MMF_ALIGN16
-#define MMF_ALIGN16 __attribute__((aligned(16)))
-#endif
-#ifndef MMF_COLD_FN
-#define MMF_COLD_FN MMF_FN         /* the device builds these out of line: they run once in 2^25 calls */
-#endif
-MMF_CONST_TABLE double mmf_acos_table[MMF_ACOS_ROWS * MMF_ACOS_STRIDE] MMF_ALIGN16 = MMF_ACOS_TABLE;
-
-// The interval of u = |x| in [0, 1 - 2^-10]: *e = its table row (constants at e[0..5]), returns h P(h) with
-// acos(u) = e[0] + e[1] + result.  One straight-line path for both regions: the region only decides the row and h.
-MMF_FN double mmf_acos_interval(double u, const double **e) {
-    const int in_a = u <= 0.5;
-    int ia = (int)(u * 128.0);
-    ia = ia > 63 ? 63 : ia;
-    const double ha = u - ((double)ia + 0.5) * 0.0078125;
-    const float zf = (float)(1.0 - u);                     // exact for a float u in (1/2, 1)
-    union { float f; unsigned u; } b;
-    b.f = zf;
-    const int ib = 64 + (int)(b.u >> 18) - 117 * 32;       // 64 + (exponent + 10) * 32 + top 5 mantissa bits
-    b.u = (b.u & 0xfffc0000u) | 0x00020000u;               // the interval's centre
-    const double hb = (double)zf - (double)b.f;
-    const double *t = mmf_acos_table + (in_a ? ia : ib) * MMF_ACOS_STRIDE;
-    const double h = in_a ? ha : hb;
-    double p = MMF_FMA(h, t[12], t[11]);
-    p = MMF_FMA(h, p, t[10]);
-    p = MMF_FMA(h, p, t[9]);
-    p = MMF_FMA(h, p, t[8]);
-    p = MMF_FMA(h, p, t[7]);
-    p = MMF_FMA(h, p, t[6]);
-    *e = t;
-    return h * p;
-}
-
-// u = |x| > 1 - 2^-10: acos(u) = s + *tail with s = sqrt(2z) rounded, z = 1 - u
-MMF_FN double mmf_acos_near_one(double u, double *tail) {
-    const double z = 1.0 - u, w = z + z;
-    const double s = MMF_SQRT(w);
-    double q = MMF_FMA(z, 35.0 / 18432.0, 5.0 / 896.0);
-    q = MMF_FMA(z, q, 3.0 / 160.0);
-    q = MMF_FMA(z, q, 1.0 / 12.0);
-    const double cr = z > 0.0 ? MMF_FMA(-s, s, w) / (s + s) : 0.0;        // the square root's own rounding error
-    *tail = MMF_FMA(s * z, q, cr);
-    return s;
-}
-
-MMF_COLD_FN float mmf_acos_f32(float x) {
-    const double u = (double)MMF_FABSF(x);
-    if (!(u <= 1.0)) return (float)MMF_ACOS_SLOW((double)x);
-    if (u > 0.9990234375) {
-        double tail;
-        const double s = mmf_acos_near_one(u, &tail);
-        if (x > 0.0f) return (float)(s + tail);
-        const double d = MMF_PI_HI - s, err = (MMF_PI_HI - d) - s;
-        return (float)(d + ((MMF_PI_LO + err) - tail));
-    }
-    const double *e;
-    const double hp = mmf_acos_interval(u, &e);
-    const int neg = x < 0.0f;
-    return (float)((neg ? e[2] : e[0]) + ((neg ? e[3] : e[1]) + (neg ? -hp : hp)));
-}
-
-MMF_COLD_FN float mmf_asin_f32(float x) {
-    const double u = (double)MMF_FABSF(x);
-    if (!(u <= 1.0)) return (float)MMF_ASIN_SLOW((double)x);
-    double r;
-    if (u < 0.0078125) {
-        // asin(u) = u + u^3 (1/6 + 3 u^2/40 + 15 u^4/336 + 105 u^6/3456): relative accuracy down to denormals
-        const double u2 = u * u;
-        double q = MMF_FMA(u2, 105.0 / 3456.0, 15.0 / 336.0);
-        q = MMF_FMA(u2, q, 3.0 / 40.0);
-        q = MMF_FMA(u2, q, 1.0 / 6.0);
-        r = MMF_FMA(u * u2, q, u);
-        if (x == 0.0f) return x;
-    } else if (u > 0.9990234375) {
-        double tail;
-        const double s = mmf_acos_near_one(u, &tail);
-        const double d = MMF_PIO2_HI - s, err = (MMF_PIO2_HI - d) - s;
-        r = d + ((MMF_PIO2_LO + err) - tail);
-    } else {
-        const double *e;
-        const double hp = mmf_acos_interval(u, &e);
-        r = e[4] + (e[5] - hp);
-    }
-    return (float)(x < 0.0f ? -r : r);
-}
-
-// low 29 bits of a double's mantissa within `band` of 0x10000000: its float rounding could go either way
+// ---- one-argument functions the platform computes: checked against glibc for every float, with an exception list ----
+// (float)f((double)x) for tan, asin, acos, atan, sinh, cosh, tanh, asinh, acosh, atanh (and sin / cos beyond the
+// table-driven range) is the device's double function (OCML) rounded to float.  OCML and glibc both carry an error of
+// well under an ulp of *double*, so their float roundings can differ only where the double result lies next to a float
+// rounding tie.  tools/libm_exceptions.py evaluates every float on the GPU and compares with the host's glibc
+// (oracle/libm_ref.c): for ROCm 7.2's OCML against glibc 2.35 the two agree on all 2^32 arguments of every one of these
+// functions except asinh (4 arguments) and acosh (2) -- mm_libm_exceptions.h lists those with glibc's float, and the
+// two functions look an argument up when the platform result is within MMF_TIE_BAND double ulps of a tie (one call in
+// 2^22).  tests/test_gpu_parity.py::test_unary_libm_equals_glibc_for_every_float repeats the enumeration: 0 differences.
+typedef struct { unsigned x, r; } mmf_exc_t;
+#include "mm_libm_exceptions.h"
+// low 29 bits of a double's mantissa within the band around 0x10000000: its float rounding could go either way
 #define MMF_TIE_BAND 64u
 MMF_FN int mmf_near_float_tie(double r) {
     union { double d; unsigned long long u; } b;
     b.d = r;
     return (((unsigned)b.u + (MMF_TIE_BAND - 0x10000000u)) & 0x1fffffffu) <= 2u * MMF_TIE_BAND;
 }
-MMF_FN float mmf_acos_fast_f32(float x) {
-    const double r = MMF_ACOS_SLOW((double)x);
-    if (mmf_near_float_tie(r) && MMF_FABSF(x) <= 1.0f) return mmf_acos_f32(x);
-    return (float)r;
+MMF_FN float mmf_exc_lookup(const mmf_exc_t *t, int n, float x, float fallback) {
+    union { float f; unsigned u; } b;
+    b.f = x;
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {                 /* sorted by argument bits */
+        const int mid = (lo + hi) >> 1;
+        if (t[mid].x == b.u) { b.u = t[mid].r; return b.f; }
+        if (t[mid].x < b.u) lo = mid + 1; else hi = mid - 1;
+    }
+    return fallback;
 }
-MMF_FN float mmf_asin_fast_f32(float x) {
-    const double r = MMF_ASIN_SLOW((double)x);
-    if (mmf_near_float_tie(r) && MMF_FABSF(x) <= 1.0f) return mmf_asin_f32(x);
-    return (float)r;
-}
+#ifndef MMF_ASINH_SLOW
+#define MMF_ASINH_SLOW(a) asinh((a))
+#define MMF_ACOSH_SLOW(a) acosh((a))
+#endif
+#define MMF_UNARY_WITH_EXCEPTIONS(name, PLATFORM)                                                        \
+    MMF_FN float mmf_##name##_f32(float x) {                                                            \
+        const double r = PLATFORM((double)x);                                                           \
+        if (mmf_near_float_tie(r)) return mmf_exc_lookup(mmf_exc_##name, MMF_EXC_N_##name, x, (float)r); \
+        return (float)r;                                                                                \
+    }
+MMF_UNARY_WITH_EXCEPTIONS(asinh, MMF_ASINH_SLOW)
+MMF_UNARY_WITH_EXCEPTIONS(acosh, MMF_ACOSH_SLOW)
 
 // ---- hypot of two float arguments ---------------------------------------------------------------------
 // (float)hypot((double)x, (double)y) as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/e_hypot.c; the x86-64 build has no
@@ -420,6 +335,9 @@ MMF_FN float mmf_asin_fast_f32(float x) {
 // 2^26 calls): everywhere else (float)h is already the result, and the division is skipped.
 #ifndef MMF_HYPOT_SLOW
 #define MMF_HYPOT_SLOW(a, b) hypot((a), (b))
+#endif
+#ifndef MMF_SQRT
+#define MMF_SQRT(a) sqrt((a))
 #endif
 MMF_FN float mmf_hypot_f32(float x, float y) {
     const double fx = (double)x, fy = (double)y;
