@@ -579,22 +579,88 @@ mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_i
                 for (auto &lv : nest) g.reenter_if(lv.first, lv.second);
                 Primary rx, ry;
                 emit_closure_render_coordinates(g, again[k].second, again[k].second.factors.empty(), &rx, &ry);
-                Rhs call;
-                call.kind = Rhs::FilterCall;
-                call.filter = def->rhs.filter;
-                call.args = def->rhs.args;
-                call.args.push_back(rx);
-                call.args.push_back(ry);
-                call.args.push_back(Primary::F(0.0f));
-                CompVar *tv = g.temp(Ty::Tuple);
-                tv->tuple_len = 4;
-                g.assign(tv, call);
-                for (int i = 0; i < 4; ++i) g.assign_op(rv[i], "TUPLE_NTH", {g.P(tv), Primary::I(i)});
+                // The closure's own code: normally a call of its filter function.  When that code calls native filters
+                // itself (the closure's calc_lines would run them from its init_frame, new_template.c.in:314-337) it is
+                // inlined instead -- user-value reads become the closure's arguments, x / y / t the render coordinates and
+                // 0.0, frame 0 -- so that its native calls sit in this kernel's frame-constant slice like any other and
+                // runtime.cpp render_closure runs them (a native filter inside a *called* function would run per pixel).
+                mmabi_filter_code_t *callee_code = nullptr;
+                {
+                    int idx = 0;
+                    for (mmabi_filter_t *gf = mathmap->filters; gf; gf = gf->next, ++idx)
+                        if (shared.filters.count(gf) && shared.filters[gf] == def->rhs.filter) callee_code = filter_codes[idx];
+                }
+                Block inl;
+                bool inline_body = false;
+                Importer impc(f->module, *sub, shared);
+                if (callee_code) {
+                    impc.block(callee_code->first_stmt, inl, nullptr);
+                    std::vector<std::pair<Stmt *, ImageChain>> inner;
+                    std::function<bool(const Block &)> has_native = [&](const Block &b) {
+                        for (const Stmt *st : b) {
+                            if (st->kind == Stmt::Assign && ((st->rhs.kind == Rhs::Closure && st->rhs.filter->kind == Filter::Native) ||
+                                                             (st->rhs.kind == Rhs::Op && !strcmp(st->rhs.op->cname, "RENDER")))) return true;
+                            if (st->kind == Stmt::If && (has_native(st->then_) || has_native(st->else_))) return true;
+                            if (st->kind == Stmt::While && has_native(st->body)) return true;
+                        }
+                        return false;
+                    };
+                    inline_body = has_native(inl);
+                }
+                if (inline_body) {
+                    Stmt *outp = nullptr;
+                    for (Stmt *st : inl)
+                        if (st->kind == Stmt::Assign && st->rhs.kind == Rhs::Op && !strcmp(st->rhs.op->cname, "OUTPUT_TUPLE")) outp = st;
+                    if (!outp || outp->rhs.args[0].kind != Primary::Val || !outp->rhs.args[0].value->def ||
+                        outp->rhs.args[0].value->def->rhs.kind != Rhs::Tuple || outp->rhs.args[0].value->def->rhs.args.size() != 4)
+                        throw CompileError("closure filter `" + def->rhs.filter->name + "' has no OUTPUT_TUPLE of a 4-tuple");
+                    const std::vector<Primary> result = outp->rhs.args[0].value->def->rhs.args;
+                    const std::vector<Primary> cargs = def->rhs.args;
+                    std::function<void(Rhs &)> subst_rhs = [&](Rhs &r) {
+                        if (r.kind == Rhs::Internal) {
+                            if (r.internal == "x") r = Rhs::P(rx);
+                            else if (r.internal == "y") r = Rhs::P(ry);
+                            else if (r.internal == "t") r = Rhs::F(0.0f);
+                            else if (r.internal == "frame") r = Rhs::I(0);
+                        } else if (r.kind == Rhs::Op && !strncmp(r.op->cname, "USERVAL_", 8) && r.args.size() == 1 &&
+                                   r.args[0].kind == Primary::IntConst) {
+                            const int ui = r.args[0].i;
+                            if (ui < 0 || ui >= (int)cargs.size()) throw CompileError("closure argument index out of range");
+                            r = Rhs::P(cargs[ui]);
+                        }
+                    };
+                    std::function<void(Block &)> subst = [&](Block &b) {
+                        for (Stmt *st : b) {
+                            if (st->kind == Stmt::Assign) subst_rhs(st->rhs);
+                            if (st->kind == Stmt::Phi) { subst_rhs(st->rhs); subst_rhs(st->rhs2); }
+                            if (st->kind == Stmt::If) { subst_rhs(st->cond); subst(st->then_); subst(st->else_); subst(st->phis); }
+                            if (st->kind == Stmt::While) { subst(st->phis); subst_rhs(st->cond); subst(st->body); }
+                        }
+                    };
+                    subst(inl);
+                    for (Stmt *st : inl)
+                        if (st != outp) g.append(st);
+                    for (int i = 0; i < 4; ++i) g.assign(rv[i], Rhs::P(result[i]));
+                } else {
+                    Rhs call;
+                    call.kind = Rhs::FilterCall;
+                    call.filter = def->rhs.filter;
+                    call.args = def->rhs.args;
+                    call.args.push_back(rx);
+                    call.args.push_back(ry);
+                    call.args.push_back(Primary::F(0.0f));
+                    CompVar *tv = g.temp(Ty::Tuple);
+                    tv->tuple_len = 4;
+                    g.assign(tv, call);
+                    for (int i = 0; i < 4; ++i) g.assign_op(rv[i], "TUPLE_NTH", {g.P(tv), Primary::I(i)});
+                }
                 for (size_t lv = 0; lv < nest.size(); ++lv) g.end_if();
                 for (int i = 0; i < 4; ++i) sub->result[i] = rv[i]->current;
-                for (auto &kv : shared.filters)
-                    if (kv.second == def->rhs.filter && std::find(shared.called.begin(), shared.called.end(), kv.first) == shared.called.end())
-                        shared.called.push_back(kv.first);
+                propagate_types(*sub);          // (tuple lengths of what was added)
+                if (!inline_body)
+                    for (auto &kv : shared.filters)
+                        if (kv.second == def->rhs.filter && std::find(shared.called.begin(), shared.called.end(), kv.first) == shared.called.end())
+                            shared.called.push_back(kv.first);
                 f->code->closure_renders.push_back(std::move(sub));
             }
             // filter_$name bodies of the filters called at run time, and of those they call (backends/cc.c:189-196

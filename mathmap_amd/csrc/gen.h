@@ -36,6 +36,8 @@ class Gen {
     void reenter_if(Stmt *s, int branch);
     void start_while(CompVar *invariant);
     void end_while();
+    // appends an already built statement (and what it contains) at the current position
+    void append(Stmt *s) { emit(s); }
 
    private:
     struct Frame {

@@ -168,7 +168,7 @@ def test_closure_arguments_are_values_of_the_current_frame_and_its_body_runs_at_
     assert np.array_equal(i2.render(t=0.9, frame=3), got)
 
 
-@pytest.mark.parametrize("name", ["blur", "render", "two", "timed_arg", "conditional_else", "conditional_then"])
+@pytest.mark.parametrize("name", ["blur", "render", "two", "timed_arg", "conditional_else", "conditional_then", "blurring_closure"])
 def test_closure_images_for_native_filters_through_the_reference_abi(name):
     """The same through gen_and_load_hip_code: the importer finds the closure images that reach native filters in the
     reference-layout IR, builds each one's render code from the main filter's code plus a call of the closure's own
@@ -176,7 +176,7 @@ def test_closure_images_for_native_filters_through_the_reference_abi(name):
     import ctypes as C
     from mathmap_amd._lib import selftest_lib
     src = {"blur": BLUR_OF_CLOSURE, "render": RENDER_OF_CLOSURE, "two": TWO_CLOSURES, "timed_arg": TIMED_ARG,
-           "conditional_else": CONDITIONAL % 1, "conditional_then": CONDITIONAL % 2}[name]
+           "conditional_else": CONDITIONAL % 1, "conditional_then": CONDITIONAL % 2, "blurring_closure": BLUR_OF_BLURRING_CLOSURE}[name]
     w, h = 192, 128
     img = np.ascontiguousarray(F.synthetic_image(w, h, seed=3))
     flt, inv = make_invocation(src, w, h, {}, {"in": img})
