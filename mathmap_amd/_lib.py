@@ -94,6 +94,7 @@ SELFTEST_SYMBOLS = {
                                                C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "mmhip_selftest_error": (C.c_char_p, []),
     "mmhip_selftest_eval_unary": (C.c_int, [C.c_int, C.c_uint, C.c_ulonglong, C.c_void_p]),
+    "mmhip_selftest_eval_binary": (C.c_int, [C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
 }
 SELFTEST_PATH = os.path.join(os.path.dirname(_HERE), "tests", "libmathmap_hip_selftest.so")
 _selftest = None

@@ -73,3 +73,55 @@ extern "C" int mmhip_selftest_eval_unary(int op, unsigned first, unsigned long l
     if (hipMemcpy(out_host, d, count * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -3;
     return 0;
 }
+
+// ---- two-argument ops on pseudo-random pairs (oracle/libm_ref.c mmo_pair generates the same pairs) ------------------
+namespace {
+enum { OP2_ATAN2, OP2_HYPOT, OP2_POW, OP2_FMOD };
+
+__device__ __forceinline__ unsigned long long splitmix_d(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ void pair_d(unsigned long long seed, unsigned long long n, float *x, float *y) {
+    const unsigned long long z = splitmix_d(seed * 0x100000001b3ULL + n);
+    unsigned a, b;
+    switch (n & 3) {
+        case 0: a = (unsigned)z; b = (unsigned)(z >> 32); break;
+        case 1: a = ((unsigned)z & 0x80ffffffu) | ((124u + (unsigned)((z >> 24) & 7)) << 23);
+                b = ((unsigned)(z >> 32) & 0x80ffffffu) | ((124u + (unsigned)((z >> 56) & 7)) << 23); break;
+        case 2: a = ((unsigned)z & 0x807fffffu) | (127u << 23);
+                b = ((unsigned)(z >> 32) & 0x807fffffu) | ((127u - (unsigned)((z >> 56) % 31)) << 23); break;
+        default: a = __float_as_uint((float)((int)(z & 0x3ff) - 512) * 0.5f); b = __float_as_uint((float)((int)((z >> 32) & 0x3ff) - 512) * 0.5f);
+    }
+    *x = __uint_as_float(a);
+    *y = __uint_as_float(b);
+}
+
+__global__ void __launch_bounds__(256) k_eval_binary(int op, unsigned long long seed, unsigned long long count, unsigned *out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
+        float x, y, r;
+        pair_d(seed, i, &x, &y);
+        switch (op) {
+            case OP2_ATAN2: r = (float)atan2((double)x, (double)y); break;      // the platform's, as mm_device.h calls it
+            case OP2_HYPOT: r = mmf_hypot_f32(x, y); break;
+            case OP2_POW: r = mmf_pow_f32(x, y); break;
+            default: r = (float)fmod((double)x, (double)y); break;
+        }
+        out[i] = __float_as_uint(r);
+    }
+}
+}  // namespace
+
+extern "C" int mmhip_selftest_eval_binary(int op, unsigned long long seed, unsigned long long count, unsigned *out_host) {
+    unsigned *d = nullptr;
+    if (hipMalloc((void **)&d, count * sizeof(unsigned)) != hipSuccess) return -1;
+    k_eval_binary<<<4096, 256>>>(op, seed, count, d);
+    int rc = 0;
+    if (hipDeviceSynchronize() != hipSuccess) rc = -2;
+    else if (hipMemcpy(out_host, d, count * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+    (void)hipFree(d);
+    return rc;
+}

@@ -235,7 +235,19 @@ MMF_FN void mmf_log_dd(double xd, double *hi, double *lo) {
     *lo = (t2 - h) + tail;                                    // Fast2Sum: |t2| >= |tail|
 }
 
+MMF_FN float mmf_pow_pos_f32(float x, float y);
 MMF_FN float mmf_pow_f32(float x, float y) {
+    // a negative base with an integer exponent is +-|x|^y (pow's definition), and |x|^y has to come out exact where it is
+    // exactly representable -- (-154.5)^3 = -3687953.625 sits on a float rounding tie, the platform's pow is an ulp off
+    // there (found by tools/libm_exceptions.py: 2094 such pairs in 4.3e9 samples)
+    if (x < 0.0f && x >= -3.40282346638528859812e38f && MMF_FABSF(y) <= 3.40282346638528859812e38f && (double)y == MMF_RINT((double)y)) {
+        const float m = mmf_pow_pos_f32(-x, y);
+        const double half = (double)y * 0.5;
+        return half == MMF_RINT(half) ? m : -m;            // even / odd exponent (every float >= 2^24 is even)
+    }
+    return mmf_pow_pos_f32(x, y);
+}
+MMF_FN float mmf_pow_pos_f32(float x, float y) {
     if (!(x > 0.0f && x <= 3.40282346638528859812e38f) || !(MMF_FABSF(y) <= 3.40282346638528859812e38f))
         return (float)MMF_POW_SLOW((double)x, (double)y);
     const double xd = (double)x, yd = (double)y;

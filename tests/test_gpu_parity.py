@@ -452,7 +452,7 @@ PROBES = [
     # hypot: glibc's own arithmetic for two floats (mm_fastmath.h); every one-argument op: equal to glibc for every float
     # (test_unary_libm_equals_glibc_for_every_float)
     ("abs(ri:[u,v])", "hypot", 0), ("abs(ri:[u*1000,v*0.001])", "hypot wide", 0),
-    ("asin(u)", "asin", 0), ("acos(v)", "acos", 0), ("asin(u*v*0.001)", "asin small", 0), ("acos(1-abs(u*v)*0.0001)", "acos near 1", 0), ("a", "polar angle", 0), ("(abs(u)+0.01)^(v*3)", "pow", 1), ("(abs(u*v)+0.5)^2", "pow int", 0), ("(abs(u)*40+0.1)^(v*9-2)", "pow wide", 1),
+    ("asin(u)", "asin", 0), ("acos(v)", "acos", 0), ("asin(u*v*0.001)", "asin small", 0), ("acos(1-abs(u*v)*0.0001)", "acos near 1", 0), ("a", "polar angle", 0), ("(abs(u)+0.01)^(v*3)", "pow", 0), ("(abs(u*v)+0.5)^2", "pow int", 0), ("(abs(u)*40+0.1)^(v*9-2)", "pow wide", 0), ("(u*9)^floor(v*6)", "pow of a negative base", 0),
     ("sinh(u*2)", "sinh", 0), ("cosh(v*2)", "cosh", 0), ("tanh(u*2)", "tanh", 0), ("u % 0.37", "fmod", 0),
 ]
 
@@ -542,6 +542,19 @@ def test_unary_libm_equals_glibc_for_every_float():
     for name, r in res.items():
         assert r["checked"] == 1 << 32
         assert r["mismatches"] == 0, (name, r["mismatches"], ["0x%08x" % x for x, _ in r["pairs"][:8]])
+
+
+def test_binary_libm_against_glibc_on_sampled_pairs():
+    """Two-argument ops cannot be enumerated: 2^28 pseudo-random pairs each (any two floats; both near 1; the second up to
+    30 binades below the first; small integers and halves, either sign) against the host's glibc.  hypot (glibc's own
+    arithmetic), pow and fmod must agree everywhere -- the full run of tools/libm_exceptions.py (2^32 pairs each,
+    profiles/r03_libm_every_float.json) found pow an ulp off at (-154.5)^3-like ties, since fixed; atan2 is the platform's
+    function: 1 differing pair in 2^32."""
+    from tools.libm_exceptions import compare_pairs
+    res = compare_pairs(runs=16, progress=False)
+    for name in ("hypot", "pow", "fmod"):
+        assert res[name]["mismatches"] == 0, (name, res[name])
+    assert res["atan2"]["mismatches"] <= 2, res["atan2"]
 
 
 # (expression, max float ulps allowed per component over ALL finite results).  0: the device runs glibc's own
