@@ -156,6 +156,15 @@ struct Generator {
         return nullptr;
     }
 
+    // "mm_native_call(A, <record>, <counters>, k, " for a call site outside loops, the dynamic form for one inside
+    std::string native_call_head(int k) const {
+        const std::string ctr = "(int *)(XY + " + std::to_string(ks.native_ctr_offset) + "), ";
+        if (!ks.natives[k].in_loop)
+            return "mm_native_call(A, XY + " + std::to_string(ks.natives[k].record_offset) + ", " + ctr + std::to_string(k) + ", ";
+        return "mm_native_call_in_loop(A, XY + " + std::to_string(ks.natives[ks.native_sites].record_offset) + ", " + ctr +
+               std::to_string(k) + ", " + std::to_string(ks.native_sites) + ", ";
+    }
+
     std::string rhs(const Rhs &r, Slice sl, const Stmt *stmt, const CompVar *lhs) {
         switch (r.kind) {
             case Rhs::Prim: return prim(r.prim, sl);
@@ -174,8 +183,7 @@ struct Generator {
                     throw CompileError("native filter `" + r.filter->name +
                                        "' is called with pixel-dependent arguments; the HIP backend needs them frame-constant");
                 int k = it->second;
-                std::string s = "mm_native_call(A, XY + " + std::to_string(ks.natives[k].record_offset) + ", " +
-                                std::to_string(k) + ", " + std::to_string(r.args.size());
+                std::string s = native_call_head(k) + std::to_string(r.args.size());
                 for (size_t i = 0; i < r.args.size(); ++i) s += ", mm_narg(" + prim(r.args[i], sl) + ")";
                 for (size_t i = r.args.size(); i < 4; ++i) s += ", mm_narg(0)";
                 return s + ")";
@@ -205,8 +213,7 @@ struct Generator {
                     if (it == native_index.end() || sl != PROLOGUE)
                         throw CompileError("render() needs frame-constant arguments in the HIP backend");
                     int k = it->second;
-                    return "mm_native_call(A, XY + " + std::to_string(ks.natives[k].record_offset) + ", " +
-                           std::to_string(k) + ", 3, mm_narg(" + prim(r.args[0], sl) + "), mm_narg(" + prim(r.args[1], sl) +
+                    return native_call_head(k) + "3, mm_narg(" + prim(r.args[0], sl) + "), mm_narg(" + prim(r.args[1], sl) +
                            "), mm_narg(" + prim(r.args[2], sl) + "), mm_narg(0))";
                 }
                 for (const char *bad : {"SOLVE_POLY_2", "SOLVE_POLY_3",      // unimplemented stubs in the reference too (opmacros.h:97-99)
@@ -446,7 +453,7 @@ struct Generator {
         return fetches >= 1 && stmts <= 12 ? 64 : 16;
     }
 
-    void find_natives(Block &b) {
+    void find_natives(Block &b, int loop_depth = 0) {
         for (Stmt *s : b) {
             if (s->kind == Stmt::Assign) {
                 bool native = (s->rhs.kind == Rhs::Closure && s->rhs.filter->kind == Filter::Native) ||
@@ -455,14 +462,15 @@ struct Generator {
                     NativeCall nc;
                     nc.func = s->rhs.kind == Rhs::Closure ? s->rhs.filter->native_func : "RENDER";
                     for (const Primary &p : s->rhs.args) nc.arg_types.push_back(p.type());
+                    nc.in_loop = loop_depth > 0;
                     native_index[s] = (int)ks.natives.size();
                     ks.natives.push_back(nc);
                 }
             } else if (s->kind == Stmt::If) {
-                find_natives(s->then_);
-                find_natives(s->else_);
+                find_natives(s->then_, loop_depth);
+                find_natives(s->else_, loop_depth);
             } else if (s->kind == Stmt::While)
-                find_natives(s->body);
+                find_natives(s->body, loop_depth + 1);
         }
     }
 
@@ -1022,7 +1030,7 @@ struct Generator {
         if (!dy || dy->rhs.kind != Rhs::Internal || dy->rhs.internal != "y") return -1;
         const Stmt *img = def_through_copies(fetch->rhs.args[2]);
         auto it = img ? native_index.find(img) : native_index.end();
-        return it == native_index.end() ? -1 : it->second;
+        return it == native_index.end() || ks.natives[it->second].in_loop ? -1 : it->second;
     }
 
     // ---- the per-row slice ------------------------------------------------------------------
@@ -1128,6 +1136,18 @@ struct Generator {
 
     void analyze_and_layout() {
         find_natives(code.body);
+        ks.native_sites = (int)ks.natives.size();
+        // A call site inside a loop makes one call per iteration, each with a result of its own (the next iteration, or
+        // the code behind the loop, may read it): such calls are numbered as the prologue makes them and recorded in
+        // dynamic entries behind the sites'.  The host runs all recorded calls in the order they were made.
+        bool any_in_loop = false;
+        for (const NativeCall &nc : ks.natives) any_in_loop = any_in_loop || nc.in_loop;
+        if (any_in_loop)
+            for (int n = 0; n < MM_NATIVE_DYN_CALLS; ++n) {
+                NativeCall nc;
+                nc.dynamic = true;
+                ks.natives.push_back(nc);
+            }
         ks.direct_native = find_direct_native();
         find_row_slice();
         std::vector<Value *> row_defs;
@@ -1144,6 +1164,10 @@ struct Generator {
         for (NativeCall &nc : ks.natives) {
             nc.record_offset = off;
             off += MM_NATIVE_REC_BYTES;
+        }
+        if (!ks.natives.empty()) {
+            ks.native_ctr_offset = off;
+            off += 16;
         }
         for (Value *v : pro_defs) {
             if (!pix_uses.count(v) || pix_def_set.count(v) || transfer_off.count(v)) continue;
@@ -1205,6 +1229,7 @@ struct Generator {
         pair_mode = opt.unroll <= 0 && !getenv("MMHIP_UNROLL") && ks.row_values == 0 && pair_eligible();   // (row values are per pixel of a pair)
         if (pair_mode) { ks.unroll = 2; pair_infer_bools(); }
         out << "#define MM_UNROLL " << ks.unroll << "\n";
+        out << "#define MM_NATIVE_REC_BYTES " << (int)MM_NATIVE_REC_BYTES << "\n#define MM_NATIVE_DYN_CALLS " << (int)MM_NATIVE_DYN_CALLS << "\n";
         // float-argument sin/cos (mm_fastmath.h), the same text the host verifier compiles; it
         // precedes the device prelude, whose complex functions use mmf_sincos_d
         out << "#define MMF_FN static __device__ __forceinline__\n#define MMF_CONST_TABLE static __device__ const\n"
@@ -1243,13 +1268,24 @@ MM_DEV mm_narg_t mm_narg(double v) { return mm_narg((float)v); }
 MM_DEV mm_narg_t mm_narg(mm_image v) { mm_narg_t a; a.kind = 2; a.i = v.idx; a.f = 0.0f; a.img = v; return a; }
 // Records a native-filter call for the host (which runs the filter's kernels between
 // the prologue and the pixel kernel) and returns the handle of its result float map.
-MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm_narg_t a0, mm_narg_t a1, mm_narg_t a2, mm_narg_t a3) {
+// ctr[0] counts the calls of this frame in the order they are made (the host runs them in that order).
+MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int *ctr, int k, int nargs, mm_narg_t a0, mm_narg_t a1, mm_narg_t a2, mm_narg_t a3) {
     int *hdr = (int *)rec;
-    hdr[0] = 1; hdr[1] = k; hdr[2] = nargs; hdr[3] = 0;
+    hdr[0] = 1; hdr[1] = k; hdr[2] = nargs; hdr[3] = ctr[0]++;
     mm_narg_t *args = (mm_narg_t *)(rec + 16);
     args[0] = a0; args[1] = a1; args[2] = a2; args[3] = a3;
     mm_image im; im.idx = A.native_slot_base + k; im.pw = A.render_width; im.ph = A.render_height;
     im.xf = im.yf = 1.0f; im.resized = 0;
+    return im;
+}
+// The same for a call site inside a loop: every call takes the next of the MM_NATIVE_DYN_CALLS dynamic entries behind
+// the `sites' call sites (record, result slot); one call too many raises ctr[2] and the host refuses the frame.
+MM_DEV mm_image mm_native_call_in_loop(const mm_args &A, char *dyn, int *ctr, int site, int sites, int nargs, mm_narg_t a0, mm_narg_t a1,
+                                       mm_narg_t a2, mm_narg_t a3) {
+    int n = ctr[1]++;
+    if (n >= MM_NATIVE_DYN_CALLS) { ctr[2] = 1; n = MM_NATIVE_DYN_CALLS - 1; }
+    mm_image im = mm_native_call(A, dyn + n * MM_NATIVE_REC_BYTES, ctr, site, nargs, a0, a1, a2, a3);
+    im.idx = A.native_slot_base + sites + n;
     return im;
 }
 // (float) frame column / row of the pixel being evaluated (render_image's per-pixel loop, builtins.c:324-333)
@@ -1273,6 +1309,10 @@ MM_DEV mm_image mm_native_call(const mm_args &A, char *rec, int k, int nargs, mm
                "    if (gid != 0) return;\n  }\n  MM_INTERNALS\n";
         if (!(fn_root ? fn_root : &code)->functions.empty()) out << "  const int col = 0, rl = 0; unsigned mm_rand_ctr = 0; (void)col; (void)rl; (void)mm_rand_ctr;\n";
         decls(pro_defs, "  ");
+        if (!ks.natives.empty()) {      // no call recorded yet this frame
+            for (const NativeCall &nc : ks.natives) out << "  *(int *)(XY + " << nc.record_offset << ") = 0;\n";
+            out << "  { int *mm_ctr = (int *)(XY + " << ks.native_ctr_offset << "); mm_ctr[0] = mm_ctr[1] = mm_ctr[2] = mm_ctr[3] = 0; }\n";
+        }
         stmts(code.body, PROLOGUE, "  ");
         for (Value *v : transfer_order)
             out << "  *(" << ctype(v->var) << " *)(XY + " << transfer_off[v] << ") = " << vname(v) << ";\n";

@@ -23,16 +23,23 @@ struct NativeCall {
     std::string func;             // "native_filter_gaussian_blur", "RENDER", ...
     std::vector<Ty> arg_types;
     int record_offset = 0;        // byte offset of its record in the frame-constant buffer
+    bool in_loop = false;         // a call site inside a `while': its calls are numbered as they happen and recorded in
+                                  // the dynamic entries (below); its own record stays unexecuted
+    bool dynamic = false;         // one of the MM_NATIVE_DYN_CALLS entries behind the call sites: the n-th call made
+                                  // from any in-loop site of this frame (the record's `index' names the site)
 };
 
-enum { MM_NATIVE_REC_BYTES = 320, MM_NATIVE_ARG_BYTES = 32, MM_NATIVE_MAX_ARGS = 9 };
+enum { MM_NATIVE_REC_BYTES = 320, MM_NATIVE_ARG_BYTES = 32, MM_NATIVE_MAX_ARGS = 9, MM_NATIVE_DYN_CALLS = 16 };
 
 struct KernelSource {
     std::string source;           // full translation unit (prelude + 2 kernels)
     std::string prologue_name, pixel_name;
     int xy_bytes = 0;             // size of the frame-constant buffer
     bool has_prologue = false;
-    std::vector<NativeCall> natives;
+    std::vector<NativeCall> natives;      // the call sites, then -- if a site sits in a loop -- MM_NATIVE_DYN_CALLS dynamic entries
+    int native_sites = 0;         // number of call sites among `natives'
+    int native_ctr_offset = -1;   // int[4] in the frame-constant buffer: calls made so far (program order), dynamic
+                                  // entries taken, "more in-loop calls than dynamic entries" flag
     int tile_w = 16, tile_h = 16;
     int unroll = 1;               // MM_UNROLL of the pixel kernel; the launch's rows per work-item is a multiple
     bool prologue_uses_time = true;   // frame-constant code reads t or frame: re-run it for every frame

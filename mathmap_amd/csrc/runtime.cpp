@@ -10,6 +10,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -203,7 +204,7 @@ int mmhip_filter_userval_info(const mmhip_filter *f, int index, mmhip_userval_in
 const char *mmhip_filter_ir_json(mmhip_filter *f) { return f->ir_json.c_str(); }
 const char *mmhip_filter_ir_json_raw(mmhip_filter *f) { return f->ir_json_raw.c_str(); }
 const char *mmhip_filter_kernel_source(mmhip_filter *f) { return f->ks.source.c_str(); }
-int mmhip_filter_num_native_calls(const mmhip_filter *f) { return (int)f->ks.natives.size(); }
+int mmhip_filter_num_native_calls(const mmhip_filter *f) { return f->ks.native_sites; }
 double mmhip_filter_jit_seconds(const mmhip_filter *f) { return f->jit_seconds; }
 
 // hiprtc-compiles one kernel source (or fetches it from the on-disk cache); 0 on success
@@ -663,6 +664,31 @@ static int rows_per_item(const KernelSource &ks, int tiles_x, int num_rows) {
 // render_image's closure branch (builtins.c:273-298): closure image #cid of the filter rendered over the
 // whole frame into a float map -- calc_lines(slice 0,0,w,h; first_row 0, last_row h; floatmap = 1) on a
 // frame made by invocation_new_frame(invocation, image, 0, 0.0): frame 0, t = 0, sampling offsets 0.
+// The native-filter calls the prologue recorded in `host' (a copy of the frame-constant buffer), in the order they
+// were made: entry k of ks.natives (a call site outside loops, or the n-th dynamic entry of the in-loop sites) and its
+// record.  The record's `pad' is the call's number within the frame (mm_native_call in hipgen.cpp).
+struct RecordedCall { size_t k; HNativeRec rec; const std::string *func; };
+static int recorded_calls(const KernelSource &ks, const std::vector<char> &host, std::vector<RecordedCall> *calls) {
+    calls->clear();
+    if (ks.natives.empty()) return 0;
+    int ctr[4];
+    memcpy(ctr, host.data() + ks.native_ctr_offset, sizeof ctr);
+    if (ctr[2])
+        return fail("native filters are called more than " + std::to_string((int)MM_NATIVE_DYN_CALLS) +
+                    " times from inside a loop of the frame-constant code: not supported");
+    for (size_t k = 0; k < ks.natives.size(); ++k) {
+        RecordedCall c;
+        c.k = k;
+        memcpy(&c.rec, host.data() + ks.natives[k].record_offset, sizeof c.rec);
+        if (!c.rec.executed) continue;
+        if (c.rec.index < 0 || c.rec.index >= ks.native_sites) return fail("internal: native call record names no call site");
+        c.func = &ks.natives[c.rec.index].func;
+        calls->push_back(c);
+    }
+    std::sort(calls->begin(), calls->end(), [](const RecordedCall &x, const RecordedCall &y) { return x.rec.pad < y.rec.pad; });
+    return 0;
+}
+
 static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const HArgs &main_args, hipStream_t s) {
     mmhip_closure_kernel &ck = f->closures[cid];
     auto &st = inv->closure_state[cid];
@@ -723,10 +749,11 @@ static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const
         std::vector<char> host(ck.ks.xy_bytes);
         HIP_TRY(hipMemcpyAsync(host.data(), st.d_xy, host.size(), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        for (size_t k = 0; k < ck.ks.natives.size(); ++k) {
-            HNativeRec rec;
-            memcpy(&rec, host.data() + ck.ks.natives[k].record_offset, sizeof rec);
-            if (!rec.executed) continue;
+        std::vector<RecordedCall> calls;
+        if (recorded_calls(ck.ks, host, &calls) != 0) return -1;
+        for (const RecordedCall &call : calls) {
+            const size_t k = call.k;
+            const HNativeRec &rec = call.rec;
             for (int i = 0; i < rec.nargs && i < 4; ++i)
                 if (rec.args[i].kind == 2 && rec.args[i].img.idx <= -2)
                     return fail("a filter closure rendered for a native filter hands another closure to a native filter: not supported");
@@ -738,7 +765,7 @@ static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const
             inv->ws.env.edge_color_y = inv->edge_color_y;
             std::string err;
             int lo = 0, hi = h;
-            if (run_native_filter(ck.ks.natives[k].func, rec, inv->images, w, h, (float *)st.native_maps[k], inv->ws, s, &err, &lo, &hi) != 0)
+            if (run_native_filter(*call.func, rec, inv->images, w, h, (float *)st.native_maps[k], inv->ws, s, &err, &lo, &hi) != 0)
                 return fail(err);
             HImageDesc &d = inv->images[st.native_slot_base + (int)k];
             d.data = st.native_maps[k];
@@ -791,10 +818,11 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         }
     }
     bool table_changed = false;
-    for (size_t k = 0; k < f->ks.natives.size(); ++k) {
-        HNativeRec rec;
-        memcpy(&rec, host.data() + f->ks.natives[k].record_offset, sizeof rec);
-        if (!rec.executed) continue;
+    std::vector<RecordedCall> calls;
+    if (recorded_calls(f->ks, host, &calls) != 0) return -1;
+    for (const RecordedCall &call : calls) {
+        const size_t k = call.k;
+        HNativeRec rec = call.rec;
         int slot = inv->native_slot_base + (int)k;
         // memo (native-filters/cache.c:110-147): same arguments on unchanged inputs -> keep the map
         // rows of the map this launch may read: everything, or -- opt-in, full-frame regions only --
@@ -880,7 +908,7 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         inv->ws.env.edge_y = f->kopt.edge_y;
         inv->ws.env.edge_color_x = inv->edge_color_x;
         inv->ws.env.edge_color_y = inv->edge_color_y;
-        int rc = run_native_filter(f->ks.natives[k].func, rec, has_closure_arg ? images_k : inv->images, a.render_width, a.render_height,
+        int rc = run_native_filter(*call.func, rec, has_closure_arg ? images_k : inv->images, a.render_width, a.render_height,
                                    (float *)inv->native_maps[k], inv->ws, s, &err, &got_lo, &got_hi, dk);
         if (rc != 0) return fail(err);
         inv->native_gen[k] = ++inv->native_gen_counter;

@@ -1,0 +1,98 @@
+"""Native filters called from inside a loop of the frame-constant code: one call per iteration, each with a result of
+its own that the next iteration (or the code behind the loop) reads.  The reference simply runs the calls as its
+init_frame code reaches them (new_template.c.in:314-337, native-filters/cache.c:110-147); here the prologue kernel
+numbers the calls as it makes them and the host runs the recorded calls in that order (hipgen.cpp mm_native_call_in_loop,
+runtime.cpp recorded_calls).  HIP through the C ABI against the oracle, and against the same chain written out."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mathmap_amd as mm
+from oracle.ccgen import CpuFilter
+from tests import filters as F
+from tests.gpu_util import make_invocation, stats
+
+pytestmark = pytest.mark.gpu
+
+# n blurs in a row; n is a user value (the loop survives into the kernel) -- and with it the number of calls
+REPEATED = """
+filter repeated (image in, int n: 0-40 (2), float s: 0-1 (0.02))
+  img = in; i = 0;
+  while i < n do img = gaussian_blur(img, s, s * (i + 1)); i = i + 1 end;
+  img(xy)
+end
+"""
+
+UNROLLED = {
+    0: "filter u (image in, float s: 0-1 (0.02)) in(xy) end",
+    1: "filter u (image in, float s: 0-1 (0.02)) p = gaussian_blur(in, s, s); p(xy) end",
+    3: "filter u (image in, float s: 0-1 (0.02)) p = gaussian_blur(in, s, s); q = gaussian_blur(p, s, s * 2); "
+       "w = gaussian_blur(q, s, s * 3); w(xy) end",
+}
+
+# a call before the loop, calls in the loop (their number follows t), a call behind the loop that reads the loop's
+# result, and a second in-loop site under a condition: the order the calls are made in is what the host must follow
+MIXED = """
+filter mixed (image in, float s: 0-1 (0.015))
+  first = gaussian_blur(in, s, s);
+  img = first; i = 0;
+  while i < 1 + t * 4 do
+    if i % 2 == 0 then img = gaussian_blur(img, s * 2, s) else img = render(img) end;
+    i = i + 1
+  end;
+  last = gaussian_blur(img, s, s * 2);
+  last(xy) * 0.5 + first(xy) * 0.5
+end
+"""
+
+
+@pytest.mark.parametrize("n", [0, 1, 3])
+def test_blur_repeated_in_a_loop_equals_the_chain_written_out(n):
+    w, h = 160, 96
+    img = F.synthetic_image(w, h, seed=5)
+    flt, inv = make_invocation(REPEATED, w, h, {"n": n}, {"in": img})
+    got = inv.render(t=0.25)
+    want = CpuFilter(flt.ir_json_raw).render(w, h, uservals={"n": n}, images={"in": img}, t=0.25)
+    assert np.array_equal(got, want), stats(got, want)
+    _, ui = make_invocation(UNROLLED[n], w, h, {}, {"in": img})
+    assert np.array_equal(got, ui.render(t=0.25))
+    # changing the count on the same invocation: fewer calls, then more
+    for m in (1, 2):
+        inv.set("n", m)
+        want = CpuFilter(flt.ir_json_raw).render(w, h, uservals={"n": m}, images={"in": img}, t=0.25)
+        assert np.array_equal(inv.render(t=0.25), want), m
+
+
+def test_calls_before_inside_and_behind_a_loop_run_in_program_order():
+    w, h = 128, 80
+    img = F.synthetic_image(w, h, seed=6)
+    flt, inv = make_invocation(MIXED, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for t in (0.0, 0.3, 0.6, 0.3):      # 1, 3, 4, 3 iterations
+        got = inv.render(t=t)
+        want = cf.render(w, h, images={"in": img}, t=t)
+        assert np.array_equal(got, want), (t, stats(got, want))
+
+
+def test_more_calls_than_dynamic_entries_is_an_error_not_a_wrong_frame():
+    w, h = 64, 48
+    img = F.synthetic_image(w, h, seed=7)
+    _, inv = make_invocation(REPEATED, w, h, {"n": 17}, {"in": img})
+    with pytest.raises(mm.MathMapError, match="more than 16 times from inside a loop"):
+        inv.render(t=0.0)
+    inv.set("n", 16)
+    inv.render(t=0.0)
+
+
+def test_loop_of_native_calls_through_the_reference_abi():
+    from mathmap_amd._lib import selftest_lib
+    w, h = 128, 80
+    img = np.ascontiguousarray(F.synthetic_image(w, h, seed=6))
+    _, inv = make_invocation(MIXED, w, h, {}, {"in": img})
+    want = inv.render(t=0.5)
+    got = np.zeros((h, w, 4), np.uint8)
+    rc = selftest_lib().mmhip_selftest_abi_roundtrip(MIXED.encode(), 1, img.ctypes.data_as(C.c_void_p), w, h, 3, w, h, 0.5, 2,
+                                                     got.ctypes.data_as(C.c_void_p))
+    assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
+    assert np.array_equal(got, want), stats(got, want)
