@@ -46,7 +46,10 @@ typedef struct mmhip_options {
     int specialize_uservals; /* 1 = JIT a kernel variant per set of scalar user values with the values baked
                                 in as literals and the reference's literal folds applied (x*0 -> 0, x+0 -> x,
                                 dead branches); off by default */
-    int reserved[7];
+    int pixel_inc;        /* drawable_get_pixel_inc (mathmap.c:1320-1327): the stride of the preview's image source
+                             (fast_image_source_scale) the bilinear fetch interpolates over (builtins.c:186-216);
+                             0 or 1 = full-resolution sources, the CLI's and every final render's case */
+    int reserved[6];
 } mmhip_options;
 
 typedef struct mmhip_userval_info {

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmathmap_hip.so")
 class Options(C.Structure):
     _fields_ = [("intersample", C.c_int), ("supersampling", C.c_int),
                 ("edge_behaviour_x", C.c_int), ("edge_behaviour_y", C.c_int),
-                ("tile_w", C.c_int), ("specialize_uservals", C.c_int), ("reserved", C.c_int * 7)]
+                ("tile_w", C.c_int), ("specialize_uservals", C.c_int), ("pixel_inc", C.c_int), ("reserved", C.c_int * 6)]
 
 
 class UservalInfo(C.Structure):
@@ -93,6 +93,7 @@ SELFTEST_SYMBOLS = {
     "mmhip_selftest_abi_roundtrip": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "mmhip_selftest_error": (C.c_char_p, []),
+    "mmhip_selftest_set_pixel_inc": (None, [C.c_int]),
     "mmhip_selftest_eval_unary": (C.c_int, [C.c_int, C.c_uint, C.c_ulonglong, C.c_void_p]),
     "mmhip_selftest_eval_binary": (C.c_int, [C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
 }
@@ -104,7 +105,7 @@ def selftest_lib():
     global _selftest
     if _selftest is None:
         lib()
-        l = C.CDLL(SELFTEST_PATH)
+        l = C.CDLL(SELFTEST_PATH, mode=C.RTLD_GLOBAL)      # it plays the host program: the backend looks host functions up by name
         for name, (res, args) in SELFTEST_SYMBOLS.items():
             fn = getattr(l, name)
             fn.restype = res

@@ -29,12 +29,14 @@ class Filter:
     """A compiled .mm filter (front-end + IR + generated HIP kernel string)."""
 
     def __init__(self, source="", intersample=True, supersampling=False, edge_x=EDGE_COLOR, edge_y=EDGE_COLOR,
-                 tile_w=0, specialize=False, constants=None, ir_json=None, _handle=None):
+                 tile_w=0, specialize=False, constants=None, ir_json=None, _handle=None, pixel_inc=1):
         """`source`: .mm text; or `ir_json`: an IR dump (mmhip_filter_ir_json_raw / the reference-ABI importer's
-        form) -- the IR-level entry point.  `constants` (name -> number) bakes scalar user values in as literals."""
+        form) -- the IR-level entry point.  `constants` (name -> number) bakes scalar user values in as literals.
+        `pixel_inc` > 1: the bilinear fetch interpolates over a source sampled at that stride (the GIMP preview's
+        fast image source, builtins.c:186-216)."""
         self._source = source
         self._kwargs = dict(intersample=intersample, supersampling=supersampling, edge_x=edge_x, edge_y=edge_y,
-                            tile_w=tile_w)
+                            tile_w=tile_w, pixel_inc=pixel_inc)
         if _handle is not None:
             self._h = _handle
             return
@@ -44,6 +46,7 @@ class Filter:
         o.supersampling = 1 if supersampling else 0
         o.edge_behaviour_x, o.edge_behaviour_y = edge_x, edge_y
         o.tile_w = tile_w
+        o.pixel_inc = pixel_inc
         o.specialize_uservals = 1 if specialize else 0
         if ir_json is not None:
             self._h = lib().mmhip_compile_ir_json(ir_json.encode(), C.byref(o))

@@ -323,7 +323,21 @@ void number_native_closures(Block &b, std::vector<std::pair<Stmt *, ImageChain>>
 }
 
 int option_key(const KernelOptions &k) {
-    return (k.intersample & 1) | ((k.supersampling & 1) << 1) | ((k.edge_x & 3) << 2) | ((k.edge_y & 3) << 4);
+    return (k.intersample & 1) | ((k.supersampling & 1) << 1) | ((k.edge_x & 3) << 2) | ((k.edge_y & 3) << 4) | (k.pixel_inc << 6);
+}
+
+// The stride of the image sources right now: the host's drawable_get_pixel_inc (mathmap.h:314; mathmap.c:1320-1327
+// answers fast_image_source_scale while the GIMP dialog is previewing, cocoa.c:58-62 always 1), which the reference's
+// compiled filters call per bilinear fetch (builtins.c:182-184).  Found in the host program by name, like the compiled
+// module's own references to host functions; a host without it has full-resolution sources.
+int host_pixel_inc(mmabi_invocation_t *inv) {
+    typedef void (*get_inc_t)(void *, void *, int *, int *);
+    static get_inc_t fn = (get_inc_t)dlsym(RTLD_DEFAULT, "drawable_get_pixel_inc");
+    if (!fn) return 1;
+    int ix = 1, iy = 1;
+    fn(inv, nullptr, &ix, &iy);
+    if (ix != iy) return -1;
+    return ix > 1 ? ix : 1;
 }
 
 Variant *get_variant(ModuleInfo *mi, mmabi_invocation_t *inv) {
@@ -335,6 +349,8 @@ Variant *get_variant(ModuleInfo *mi, mmabi_invocation_t *inv) {
     // reference: COLOR=1 WRAP=2 REFLECT=3 ROTATE=4
     ko.edge_x = ko.edge_x >= 1 && ko.edge_x <= 4 ? ko.edge_x - 1 : 0;
     ko.edge_y = ko.edge_y >= 1 && ko.edge_y <= 4 ? ko.edge_y - 1 : 0;
+    ko.pixel_inc = host_pixel_inc(inv);
+    if (ko.pixel_inc < 0 || ko.pixel_inc > 4096) { host_error("HIP backend: drawable_get_pixel_inc answered strides the backend does not take"); return nullptr; }
     Variant &v = mi->variants[option_key(ko)];
     if (!v.flt) {
         std::string err;
@@ -702,9 +718,31 @@ mmabi_initfunc_t gen_and_load_hip_code(mmabi_mathmap_t *mathmap, void **module_i
         return nullptr;
     }
     for (auto &p : prebuilt) mi->variants[p.first].flt = p.second;
-    mi->build = [](const KernelOptions &, std::string *err) -> mmhip_filter * {
-        *err = "kernel variant was not prepared";
-        return nullptr;
+    // Variants beyond the prepared ones differ in the source stride only (drawable_get_pixel_inc > 1: the dialog's
+    // preview): built when first asked for, from the IR dump of the prepared variant with the same other options.
+    ModuleInfo *mip = mi.get();
+    mi->build = [mip](const KernelOptions &ko, std::string *err) -> mmhip_filter * {
+        KernelOptions base = ko;
+        base.pixel_inc = 1;
+        auto it = mip->variants.find(option_key(base));
+        if (ko.pixel_inc <= 1 || it == mip->variants.end() || !it->second.flt) {
+            *err = "kernel variant was not prepared";
+            return nullptr;
+        }
+        const mmhip_filter *b = it->second.flt;
+        mmhip_filter *f = mmhip_filter_new_empty();
+        try {
+            f->code.reset(new FilterCode());
+            load_ir_json(f->module, *f->code, (b->ir_json_raw.empty() ? b->ir_json : b->ir_json_raw).c_str());
+            if (!mmhip_filter_finalize(f, ko, err)) throw CompileError(*err);
+            f->specialize = b->specialize;
+            f->spec_min_uses = b->spec_min_uses;
+        } catch (const std::exception &e) {
+            *err = e.what();
+            mmhip_filter_free(f);
+            return nullptr;
+        }
+        return f;
     };
     *module_info = mi.release();
     return hip_mathmapinit;

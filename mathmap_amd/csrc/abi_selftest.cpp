@@ -288,6 +288,12 @@ extern "C" {
 
 const char *mmhip_selftest_error(void) { return g_selftest_err.c_str(); }
 
+// the host's drawable_get_pixel_inc (mathmap.h:314; mathmap.c:1320-1327): the stride of the image sources, > 1 while
+// the GIMP dialog previews.  The backend finds it by name, like a compiled module would.
+static int g_pixel_inc = 1;
+void drawable_get_pixel_inc(void *, void *, int *inc_x, int *inc_y) { *inc_x = *inc_y = g_pixel_inc; }
+void mmhip_selftest_set_pixel_inc(int inc) { g_pixel_inc = inc; }
+
 // the host's error buffer: the backend reports through it like the reference's backends do (exprtree.c:40, cc.c:653-693)
 char error_string[1024];
 
@@ -493,7 +499,11 @@ int mmhip_selftest_abi_roundtrip(const char *source, int intersample, const uint
         // so with several bands only the first max-band-height entries are set
         int expect = 0;
         for (int b = 0; b < num_bands; ++b) expect = std::max(expect, h * (b + 1) / num_bands - h * b / num_bands);
-        if (finished != expect) { g_selftest_err = "rows_finished bookkeeping differs from the template's"; return -2; }
+        if (finished != expect) {
+            g_selftest_err = "rows_finished bookkeeping differs from the template's";
+            if (error_string[0]) g_selftest_err += std::string(" (the backend reported: ") + error_string + ")";
+            return -2;
+        }
         return 0;
     } catch (const std::exception &e) {
         g_selftest_err = e.what();

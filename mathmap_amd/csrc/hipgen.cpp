@@ -1224,6 +1224,7 @@ struct Generator {
         out << "#define MM_INTERSAMPLE " << opt.intersample << "\n";
         out << "#define MM_SUPERSAMPLING " << opt.supersampling << "\n";
         out << "#define MM_EDGE_X " << opt.edge_x << "\n#define MM_EDGE_Y " << opt.edge_y << "\n";
+        if (opt.pixel_inc > 1) out << "#define MM_PIXEL_INC " << opt.pixel_inc << "\n";
         out << "#define MM_TILE_W " << ks.tile_w << "\n#define MM_TILE_H " << ks.tile_h << "\n";
         ks.unroll = opt.unroll > 0 ? opt.unroll : auto_unroll();
         pair_mode = opt.unroll <= 0 && !getenv("MMHIP_UNROLL") && ks.row_values == 0 && pair_eligible();   // (row values are per pixel of a pair)

@@ -12,6 +12,7 @@ struct KernelOptions {
     int intersample = 1;      // bilinear input fetch (CLI flag -i)
     int supersampling = 0;
     int edge_x = 0, edge_y = 0;
+    int pixel_inc = 1;        // stride of the image sources the bilinear fetch interpolates over (the GIMP preview's fast source)
     int tile_w = 0;           // pixels per workgroup row (0: chosen from the body, auto_tile_w); tile_h = 256 / tile_w
     int unroll = 0;           // pixels evaluated back to back per work-item step; 0 = choose (hipgen.cpp auto_unroll)
     bool hoist = true;        // evaluate frame-constant code once per frame in a prologue kernel

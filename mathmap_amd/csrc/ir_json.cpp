@@ -316,6 +316,7 @@ extern "C" mmhip_filter *mmhip_compile_ir_json(const char *json, const mmhip_opt
             ko.supersampling = opts->supersampling;
             ko.edge_x = opts->edge_behaviour_x;
             ko.edge_y = opts->edge_behaviour_y;
+            ko.pixel_inc = opts->pixel_inc > 1 ? opts->pixel_inc : 1;
             if (opts->tile_w) ko.tile_w = opts->tile_w;
         }
         std::string err;

@@ -666,6 +666,22 @@ MM_DEV mm_bilinear mm_intersample_sums_hot(const mm_args &A, const mm_image_desc
     // `bad`: the caller discards this result and re-evaluates the pixel on the generic path.  Such a lane goes on
     // with coordinate 0, so that whatever the pixel body does with the discarded value stays tame: every lane's
     // weights are in [0, 1] and its sums in [0, 255.001).
+#ifdef MM_PIXEL_INC
+    // The preview's strided source (builtins.c:186-216, drawable_get_pixel_inc > 1): taps MM_PIXEL_INC apart on the grid
+    // of multiples of the stride, weights in units of the stride.  Coordinates beyond +-2^30 px go to the generic path.
+    x = (float)((double)x - MM_PIXEL_INC / 2.0);
+    y = (float)((double)y - MM_PIXEL_INC / 2.0);
+    const bool ok_x = fabsf(x) < 1073741824.0f, ok_y = fabsf(y) < 1073741824.0f;
+    bad = bad || !ok_x || !ok_y;
+    x = ok_x ? x : 0.0f;
+    y = ok_y ? y : 0.0f;
+    const int x1 = (int)(floor((double)(x / (float)MM_PIXEL_INC)) * (double)MM_PIXEL_INC), x2 = x1 + MM_PIXEL_INC;
+    const int y1 = (int)(floor((double)(y / (float)MM_PIXEL_INC)) * (double)MM_PIXEL_INC), y2 = y1 + MM_PIXEL_INC;
+    const color_t p1 = mm_get_pixel(A, d, x1, y1), p2 = mm_get_pixel(A, d, x1, y2);
+    const color_t p3 = mm_get_pixel(A, d, x2, y1), p4 = mm_get_pixel(A, d, x2, y2);
+    mm_f2 rg, ba;
+    mm_bilinear_sums(p1, p2, p3, p4, (x - (float)x1) / (float)MM_PIXEL_INC, (y - (float)y1) / (float)MM_PIXEL_INC, rg, ba);
+#else
     const bool ok_x = fabsf(x) < 2147483648.0f, ok_y = fabsf(y) < 2147483648.0f;
     bad = bad || !ok_x || !ok_y;
     x = ok_x ? x : 0.0f;
@@ -680,9 +696,16 @@ MM_DEV mm_bilinear mm_intersample_sums_hot(const mm_args &A, const mm_image_desc
     }
     mm_f2 rg, ba;
     mm_bilinear_sums(p1, p2, p3, p4, x - x1, y - y1, rg, ba);
+#endif
     mm_bilinear r;      // rintf of a sum in [0, 255.001) is a byte: (color_t)rintf(v) & 0xff changes nothing
     r.rg = mm_f2{rintf(rg.x), rintf(rg.y)};
     r.ba = mm_f2{rintf(ba.x), rintf(ba.y)};
+#ifdef MM_PIXEL_INC
+    // the float quotient x / stride may round up to an integer the exact one stays below: a weight of -1 ulp then, a sum
+    // that rounds to -0.0 where the reference's (color_t) conversion yields byte 0
+    r.rg = r.rg + mm_f2{0.0f, 0.0f};
+    r.ba = r.ba + mm_f2{0.0f, 0.0f};
+#endif
     return r;
 }
 
@@ -692,10 +715,21 @@ MM_DEV mm_bilinear mm_intersample_sums_hot(const mm_args &A, const mm_image_desc
 MM_DEV mm_tup<4> mm_intersample_tuple_cold(const mm_args &A, const mm_image_desc &d, float x, float y, int frame) {
     x = (x + d.middle_x) * d.scale_x;
     y = -((y - d.middle_y) * d.scale_y);
+#ifdef MM_PIXEL_INC
+    // builtins.c:186-216 with drawable_get_pixel_inc > 1 (the preview's strided source), operation for operation: the
+    // half-stride shift in double, the float division by the stride, floor and the product in double, x86's conversion
+    x = (float)((double)x - MM_PIXEL_INC / 2.0);
+    y = (float)((double)y - MM_PIXEL_INC / 2.0);
+    const int x1 = mm_d2i(floor((double)(x / (float)MM_PIXEL_INC)) * (double)MM_PIXEL_INC), x2 = (int)((unsigned)x1 + MM_PIXEL_INC);
+    const int y1 = mm_d2i(floor((double)(y / (float)MM_PIXEL_INC)) * (double)MM_PIXEL_INC), y2 = (int)((unsigned)y1 + MM_PIXEL_INC);
+    const float x2fact = (x - (float)x1) / (float)MM_PIXEL_INC, y2fact = (y - (float)y1) / (float)MM_PIXEL_INC;
+#else
     const int x1 = mm_f2i(floorf(x)), x2 = x1 + 1;     // == (int)floor((double)x) on x86-64
     const int y1 = mm_f2i(floorf(y)), y2 = y1 + 1;
+    const float x2fact = x - x1, y2fact = y - y1;
+#endif
     const bool wild = x1 == (int)0x80000000 || y1 == (int)0x80000000;
-#if MM_EDGE_X == 0 && MM_EDGE_Y == 0 && !defined(MM_NO_OUTSIDE_SHORTCUT)
+#if MM_EDGE_X == 0 && MM_EDGE_Y == 0 && !defined(MM_NO_OUTSIDE_SHORTCUT) && !defined(MM_PIXEL_INC)      // (it knows the taps as x1, x1 + 1)
     // Every lane of the wave entirely outside a bound image (most fetches of Droste's level loop): get_pixel answers
     // x outside -> edge colour x, else y outside -> edge colour y, so a lane whose two columns are both outside has
     // four taps of edge colour x, one whose columns are both inside and whose rows are both outside four of edge
@@ -720,7 +754,7 @@ MM_DEV mm_tup<4> mm_intersample_tuple_cold(const mm_args &A, const mm_image_desc
     if (__builtin_amdgcn_ballot_w64(wild || p1 != p2 || p1 != p3 || p1 != p4) == 0) return mm_tuple_from_color(p1);
 #endif
     mm_f2 rg, ba;
-    mm_bilinear_sums(p1, p2, p3, p4, x - x1, y - y1, rg, ba);
+    mm_bilinear_sums(p1, p2, p3, p4, x2fact, y2fact, rg, ba);
     rg = mm_f2{rintf(rg.x), rintf(rg.y)};
     ba = mm_f2{rintf(ba.x), rintf(ba.y)};
     if (wild)      // invalid coordinate: garbage sums, exact conversion

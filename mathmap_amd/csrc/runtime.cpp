@@ -101,6 +101,7 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
             ko.supersampling = opts->supersampling;
             ko.edge_x = opts->edge_behaviour_x;
             ko.edge_y = opts->edge_behaviour_y;
+            ko.pixel_inc = opts->pixel_inc > 1 ? opts->pixel_inc : 1;
             if (opts->tile_w) ko.tile_w = opts->tile_w;
             f->opts = *opts;
             f->specialize = opts->specialize_uservals != 0;

@@ -415,7 +415,7 @@ class _Args(C.Structure):
                 ("edge_behaviour_x", C.c_int), ("edge_behaviour_y", C.c_int), ("edge_color_x", C.c_uint),
                 ("edge_color_y", C.c_uint), ("uservals", C.POINTER(_Userval)), ("images", C.POINTER(_ImageDesc)),
                 ("num_images", C.c_int), ("native_slot_base", C.c_int), ("memo", C.POINTER(_Memo)),
-                ("curves", C.c_void_p), ("gradients", C.c_void_p), ("closure_base", C.c_int)]
+                ("curves", C.c_void_p), ("gradients", C.c_void_p), ("closure_base", C.c_int), ("pixel_inc", C.c_int)]
 
 
 def _run(cmd):
@@ -526,7 +526,7 @@ class CpuFilter:
 
     def render(self, width, height, uservals=None, images=None, t=0.0, frame=0, intersample=True, threads=1,
                bpp=4, floatmap=False, edge=(0, 0), edge_colors=(0, 0), rows=None, timing=None,
-               region_width=None, sampling_offset=(0.0, 0.0), supersampling=False, render_size=None):
+               region_width=None, sampling_offset=(0.0, 0.0), supersampling=False, render_size=None, pixel_inc=1):
         """Renders on the CPU.  `uservals`: {name: value}; `images`: {name: uint8 [H,W,3|4]}.
         `threads` > 1 splits the rows into contiguous bands like call_invocation_parallel
         (mathmap_common.c:972-1006).  Returns uint8 [H,W,bpp] or float32 [H,W,4]."""
@@ -592,7 +592,7 @@ class CpuFilter:
             for sub in self.subs:
                 m = sub.render(a_img_w, a_img_h, uservals=uservals, images=images, t=t, frame=frame, intersample=intersample,
                                floatmap=True, edge=edge, edge_colors=edge_colors, supersampling=supersampling,
-                               render_size=render_size)
+                               render_size=render_size, pixel_inc=pixel_inc)
                 keep.append(m)
                 d = _ImageDesc()
                 d.data, d.w, d.h, d.kind, d.num_frames, d.channels = m.ctypes.data, m.shape[1], m.shape[0], 1, 1, 4
@@ -628,6 +628,7 @@ class CpuFilter:
         gtab = np.ascontiguousarray(np.concatenate(grads).astype(np.uint32)) if grads else np.zeros(1, np.uint32)
         a.curves, a.gradients = ctab.ctypes.data, gtab.ctypes.data
         a.closure_base = closure_base
+        a.pixel_inc = pixel_inc
         out = np.zeros((height, rw, 4), np.float32) if floatmap else np.zeros((height, rw, bpp), np.uint8)
         xy = C.create_string_buffer(max(self.lib.mmo_xy_size(), 16))
         r0, r1 = rows if rows is not None else (0, height)

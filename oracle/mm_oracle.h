@@ -88,6 +88,7 @@ typedef struct {
     const float *curves;
     const color_t *gradients;
     int closure_base;            /* image-table slot of closure image #0 rendered for native filters, or -1 */
+    int pixel_inc;               /* drawable_get_pixel_inc (mathmap.c:1320-1327): fast_image_source_scale while previewing, else 1 (0 = 1) */
 } mmo_args;
 
 /* ---- op macros (opmacros.h) ---- */

@@ -163,13 +163,28 @@ color_t mmo_get_orig_val_intersample_pixel(const mmo_args *A, float x, float y, 
     float x2fact, y2fact, x1fact, y1fact, p1fact, p2fact, p3fact, p4fact;
     color_t pixel1, pixel2, pixel3, pixel4;
     float r, g, b, a;
+    int pixel_inc_x = A->pixel_inc > 1 ? A->pixel_inc : 1, pixel_inc_y = pixel_inc_x;     /* builtins.c:182-184 */
     if (d != NULL && d->kind != MMO_IMG_NULL) to_pixel_coords(d, &x, &y);
-    x1 = floor(x);
-    x2 = x1 + 1;
-    x2fact = x - x1;
-    y1 = floor(y);
-    y2 = y1 + 1;
-    y2fact = y - y1;
+    if (pixel_inc_x > 1) {       /* builtins.c:186-194: the preview's strided source */
+        x -= pixel_inc_x / 2.0;
+        x1 = floor(x / pixel_inc_x) * pixel_inc_x;
+        x2 = x1 + pixel_inc_x;
+        x2fact = (x - x1) / pixel_inc_x;
+    } else {
+        x1 = floor(x);
+        x2 = x1 + 1;
+        x2fact = x - x1;
+    }
+    if (pixel_inc_y > 1) {       /* builtins.c:203-211 */
+        y -= pixel_inc_y / 2.0;
+        y1 = floor(y / pixel_inc_y) * pixel_inc_y;
+        y2 = y1 + pixel_inc_y;
+        y2fact = (y - y1) / pixel_inc_y;
+    } else {
+        y1 = floor(y);
+        y2 = y1 + 1;
+        y2fact = y - y1;
+    }
     x1fact = 1.0 - x2fact;
     y1fact = 1.0 - y2fact;
     p1fact = x1fact * y1fact;

@@ -715,3 +715,61 @@ end
                                                      got.ctypes.data_as(C.c_void_p))
     msg = selftest_lib().mmhip_selftest_error().decode()
     assert rc != 0 and ("loop" in msg or "frame-constant" in msg), msg
+
+
+@pytest.mark.parametrize("inc", [1, 2, 3, 5])
+def test_oracle_strided_bilinear_fetch_against_a_numpy_restatement(inc):
+    """get_orig_val_intersample_pixel with drawable_get_pixel_inc = inc (builtins.c:182-245; the GIMP preview's strided
+    source): the oracle's C function called directly on random pixel coordinates (identity pixel mapping: scale 1,
+    middle 0), against the same arithmetic restated in numpy with every rounding spelled out.  No reference vector
+    exists for this branch (only the GIMP dialog reaches it)."""
+    import ctypes as C
+    from oracle import ccgen
+    lib = ccgen.runtime_library()
+    fn = lib.mmo_get_orig_val_intersample_pixel
+    fn.restype = C.c_uint
+    fn.argtypes = [C.POINTER(ccgen._Args), C.c_float, C.c_float, C.POINTER(ccgen._ImageDesc), C.c_int]
+    rng = np.random.default_rng(40 + inc)
+    w, h = 37, 23
+    img = np.ascontiguousarray(rng.integers(0, 256, (h, w, 4), dtype=np.uint8))
+    d = ccgen._ImageDesc()
+    d.data, d.w, d.h, d.kind, d.num_frames, d.channels = img.ctypes.data, w, h, 0, 1, 4
+    d.scale_x = d.scale_y = 1.0
+    d.middle_x = d.middle_y = 0.0
+    a = ccgen._Args()
+    a.pixel_inc = inc
+    a.edge_color_x, a.edge_color_y = 0x11223344, 0x55667788
+    f32 = np.float32
+
+    def tap(x, y):
+        if x < 0 or x >= w:
+            return [(a.edge_color_x >> s) & 0xff for s in (24, 16, 8, 0)]
+        if y < 0 or y >= h:
+            return [(a.edge_color_y >> s) & 0xff for s in (24, 16, 8, 0)]
+        return [int(v) for v in img[y, x]]
+
+    def axis(v):
+        if inc > 1:
+            v = f32(np.float64(v) - inc / 2.0)
+            v1 = int(np.floor(np.float64(f32(v / f32(inc)))) * inc)
+            return v1, v1 + inc, f32(f32(v - f32(v1)) / f32(inc))
+        v1 = int(np.floor(np.float64(v)))
+        return v1, v1 + 1, f32(v - f32(v1))
+
+    for _ in range(4000):
+        x, y = f32(rng.uniform(-6, w + 6)), f32(rng.uniform(-6, h + 6))
+        if rng.integers(0, 4) == 0:
+            x = f32(np.round(x))                 # on the grid
+        x1, x2, fx = axis(x)
+        y1, y2, fy = axis(f32(-f32(-y)))         # the pixel mapping negates y: pass -y, get y
+        gx, gy = f32(f32(1.0) - fx), f32(f32(1.0) - fy)
+        weights = [f32(gx * gy), f32(gx * fy), f32(fx * gy), f32(fx * fy)]
+        taps = [tap(x1, y1), tap(x1, y2), tap(x2, y1), tap(x2, y2)]
+        want = 0
+        for c in range(4):
+            acc = f32(f32(taps[0][c]) * weights[0])
+            for k in (1, 2, 3):
+                acc = f32(acc + f32(f32(taps[k][c]) * weights[k]))
+            want = (want << 8) | (int(np.rint(acc)) & 0xff)
+        got = fn(C.byref(a), float(x), float(-y), C.byref(d), 0)
+        assert got == want, (inc, float(x), float(y), hex(got), hex(want))

@@ -305,6 +305,55 @@ def test_nan_and_huge_coordinates_follow_x86_conversion(intersample):
         assert np.array_equal(got, want), (src[:40], ex, ey, stats(got, want))
 
 
+@pytest.mark.parametrize("inc", [2, 3, 4, 7])
+def test_preview_strided_sampling_matches_oracle(inc):
+    """drawable_get_pixel_inc > 1 (the GIMP dialog's preview reads a source sampled at fast_image_source_scale,
+    mathmap.c:1320-1327): the bilinear fetch takes its taps `inc` apart on the grid of multiples of inc and weighs in
+    units of inc (builtins.c:186-216).  The branch-free hot fetch, the pixel that is one fetch, the early-exit fetch
+    (Droste; the one-pixel kernel shape), every edge behaviour, NaN / huge coordinates: bit-exact against the oracle;
+    and a frame that differs from the full-resolution one (the option is live)."""
+    w, h = 160, 96
+    img = F.synthetic_image(53, 37, seed=21)
+    colors = (0x20406080, 0xC0A01055)
+    scaled = "filter e (image in) in(xy * 1.3 + xy:[0.11, -0.07]) end"
+    mixed = "filter e (image in) in(xy * 2.7 + xy:[0.31, -0.23]) * 0.75 + in(xy * 0.8) * 0.25 end"
+    wild = ("filter n (image in) q = exp(x * 1000 + 900); big = x * 1000000 * 1000000 * 1000000 * 1000000 * 1000000; "
+            "in(xy + xy:[q, 0]) * 0.5 + in(xy:[big, y]) * 0.25 + in(xy + xy:[q * 0, 0]) * 0.25 end")
+    for src in (scaled, mixed, wild):
+        for ex, ey in ((0, 0), (1, 2), (3, 3)):
+            flt = mm.Filter(src, edge_x=ex, edge_y=ey, pixel_inc=inc)
+            inv = flt.invoke(w, h)
+            inv.set_image("in", img)
+            inv.set_edge_colors(*colors)
+            got = inv.render()
+            want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, edge=(ex, ey), edge_colors=colors, pixel_inc=inc)
+            assert np.array_equal(got, want), (src[:40], ex, ey, stats(got, want))
+    plain = mm.Filter(scaled).invoke(w, h)
+    plain.set_image("in", img)
+    flt = mm.Filter(scaled, pixel_inc=inc)
+    inv = flt.invoke(w, h)
+    inv.set_image("in", img)
+    assert not np.array_equal(inv.render(), plain.render())
+    # the early-exit fetch: Droste's body, and the one-pixel kernel shape
+    big = F.synthetic_image(w, h, seed=4)
+    flt = F.load("droste", pixel_inc=inc)
+    inv = flt.invoke(w, h)
+    inv.set_image("in", big)
+    want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": big}, pixel_inc=inc)
+    assert np.array_equal(inv.render(), want), stats(inv.render(), want)
+    import os
+    os.environ["MMHIP_SINGLE_PIXEL"] = "1"
+    try:
+        flt = mm.Filter(mixed + " ", edge_x=2, edge_y=1, pixel_inc=inc)
+        inv = flt.invoke(w, h)
+        inv.set_image("in", img)
+        inv.set_edge_colors(*colors)
+        want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, edge=(2, 1), edge_colors=colors, pixel_inc=inc)
+        assert np.array_equal(inv.render(), want)
+    finally:
+        del os.environ["MMHIP_SINGLE_PIXEL"]
+
+
 @pytest.mark.parametrize("size", [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (17, 2)])
 def test_degenerate_frame_sizes(size):
     """One-pixel-wide / -high frames: (W-1)/2 = 0 makes the virtual coordinates inf or NaN in the
@@ -405,6 +454,36 @@ def test_reference_abi_boundary_roundtrip(name, bands, marlene):
     oracle = CpuFilter(flt.ir_json_raw).render(w, h, uservals=tables, images={"in": marlene} if needs else {}, t=0.25)
     mx, nd, n1 = stats(got, oracle)
     EXP_ORACLE.check("abi/%s/256x256" % name, mx, nd, n1, got.size, default=(1, 0))
+
+
+def test_reference_abi_tier_asks_the_host_for_the_preview_stride(marlene):
+    """The reference's compiled filters call the host's drawable_get_pixel_inc per bilinear fetch (builtins.c:182-184);
+    the HIP backend asks it once per frame and runs the kernel variant of that stride.  The self-test host answers 3,
+    then 1 again (the dialog's preview followed by the final render on the same module)."""
+    import ctypes as C
+    from mathmap_amd._lib import selftest_lib
+    w, h = 192, 128
+    src = "filter e (image in) in(xy * 1.3 + xy:[0.11, -0.07]) * 0.75 + in(xy * 0.6) * 0.25 end"
+    img = np.ascontiguousarray(marlene)
+
+    def through_abi():
+        got = np.zeros((h, w, 4), np.uint8)
+        rc = selftest_lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0], 3,
+                                                         w, h, 0.25, 2, got.ctypes.data_as(C.c_void_p))
+        assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
+        return got
+
+    frames = {}
+    try:
+        for inc in (3, 1):
+            selftest_lib().mmhip_selftest_set_pixel_inc(inc)
+            frames[inc] = through_abi()
+            flt = mm.Filter(src, pixel_inc=inc)
+            want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": marlene}, t=0.25, pixel_inc=inc)
+            assert np.array_equal(frames[inc], want), (inc, stats(frames[inc], want))
+    finally:
+        selftest_lib().mmhip_selftest_set_pixel_inc(1)
+    assert not np.array_equal(frames[1], frames[3])
 
 
 def test_reference_abi_tier_specialises_from_the_second_frame(marlene):
