@@ -14,6 +14,8 @@
 #include <functional>
 #include <map>
 #include <set>
+#include <stdexcept>
+#include <algorithm>
 
 #include "passes.h"
 
@@ -401,9 +403,110 @@ static bool hoist_speculative(FilterCode &code) {
     return moved_any;
 }
 
+// A native-filter call (or render()) whose arguments are frame constants, sitting under pixel-dependent control --
+// `if inside then b = gaussian_blur(in, s, s); b(xy) else in(xy) end`.  The reference runs the filter when the first
+// pixel reaches the call and finds it in the cache from then on (native-filters/cache.c:110-147); the result does not
+// depend on which pixel that was.  Here the call moves, with the pure statements that prepare its arguments, in front
+// of the outermost pixel-dependent statement around it -- staying inside any frame-constant conditional further out --
+// and so into the frame-constant slice: run once per frame, before the pixel kernel.  (Speculative if no pixel takes
+// the branch: a blur too many, never a different pixel.)  Calls whose arguments depend on the pixel stay where they
+// are and are refused by the code generator.
+static bool is_native_call(const Stmt *s) {
+    if (s->kind != Stmt::Assign) return false;
+    if (s->rhs.kind == Rhs::Closure) return s->rhs.filter->kind == Filter::Native;
+    return s->rhs.kind == Rhs::Op && !strcmp(s->rhs.op->cname, "RENDER");
+}
+
+static bool hoist_native_calls(FilterCode &code) {
+    auto prim_const = [](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted; };
+    auto cond_const = [&](const Stmt *c) {
+        if (c->cond.kind == Rhs::Prim) return prim_const(c->cond.prim);
+        if (c->cond.kind == Rhs::Internal) return internal_is_frame_const(c->cond.internal);
+        for (const Primary &p : c->cond.args)
+            if (!prim_const(p)) return false;
+        return c->cond.kind != Rhs::Op || c->cond.op->pure;
+    };
+    // candidates first (the tree is edited afterwards)
+    std::vector<std::pair<Stmt *, Stmt *>> work;      // (call, outermost pixel-dependent statement around it)
+    std::vector<Stmt *> stack;
+    std::function<void(Block &)> find = [&](Block &b) {
+        for (Stmt *s : b) {
+            if (is_native_call(s) && !s->lhs->hoisted) {
+                for (Stmt *anc : stack)
+                    if (!cond_const(anc)) { work.push_back({s, anc}); break; }
+            }
+            if (s->kind == Stmt::If) { stack.push_back(s); find(s->then_); find(s->else_); stack.pop_back(); }
+            if (s->kind == Stmt::While) { stack.push_back(s); find(s->body); stack.pop_back(); }
+        }
+    };
+    find(code.body);
+    bool moved_any = false;
+    for (auto &w : work) {
+        Stmt *call = w.first, *outer = w.second;
+        std::set<const Stmt *> inside;
+        std::function<void(Block &)> collect = [&](Block &b) {
+            for (Stmt *s : b) {
+                inside.insert(s);
+                if (s->kind == Stmt::If) { collect(s->then_); collect(s->else_); collect(s->phis); }
+                if (s->kind == Stmt::While) { collect(s->phis); collect(s->body); }
+            }
+        };
+        collect(outer->then_); collect(outer->else_); collect(outer->phis); collect(outer->body);
+        if (!inside.count(call)) continue;      // moved along with an earlier call
+        // the call and what prepares its arguments inside `outer', definitions before uses
+        std::vector<Stmt *> order;
+        std::set<const Stmt *> seen;
+        bool ok = true;
+        std::function<void(Stmt *)> need = [&](Stmt *s) {
+            if (!ok || seen.count(s)) return;
+            seen.insert(s);
+            const bool fine = s->kind == Stmt::Assign &&
+                              (s == call || s->rhs.kind == Rhs::Prim || s->rhs.kind == Rhs::Tuple || is_native_call(s) ||
+                               (s->rhs.kind == Rhs::Internal && internal_is_frame_const(s->rhs.internal)) ||
+                               (s->rhs.kind == Rhs::Op && s->rhs.op->pure && strcmp(s->rhs.op->cname, "ORIG_VAL")));
+            if (!fine) { ok = false; return; }
+            std::vector<Primary> ps = s->rhs.args;
+            if (s->rhs.kind == Rhs::Prim) ps.push_back(s->rhs.prim);
+            for (const Primary &p : ps) {
+                if (p.kind != Primary::Val || p.value->index < 0) continue;
+                if (p.value->def && inside.count(p.value->def)) need(p.value->def);
+                else if (!p.value->hoisted) ok = false;
+                if (!ok) return;
+            }
+            order.push_back(s);
+        };
+        need(call);
+        if (!ok) continue;
+        // out of their blocks ...
+        std::function<void(Block &)> strip = [&](Block &b) {
+            for (size_t i = 0; i < b.size(); ++i) {
+                Stmt *s = b[i];
+                if (seen.count(s)) { b.erase(b.begin() + i); --i; continue; }
+                if (s->kind == Stmt::If) { strip(s->then_); strip(s->else_); }
+                if (s->kind == Stmt::While) strip(s->body);
+            }
+        };
+        strip(outer->then_); strip(outer->else_); strip(outer->body);
+        // ... and in front of `outer'
+        Block *home = &code.body;
+        if (Stmt *p = outer->parent) {
+            if (std::find(p->then_.begin(), p->then_.end(), outer) != p->then_.end()) home = &p->then_;
+            else if (std::find(p->else_.begin(), p->else_.end(), outer) != p->else_.end()) home = &p->else_;
+            else home = &p->body;
+        }
+        auto at = std::find(home->begin(), home->end(), outer);
+        if (at == home->end()) throw std::runtime_error("internal: statement not found in its parent's block");
+        for (Stmt *s : order) s->parent = outer->parent;
+        home->insert(at, order.begin(), order.end());
+        moved_any = true;
+    }
+    return moved_any;
+}
+
 void analyze_frame_constants(FilterCode &code) {
     analyze_frame_constants_once(code);
     if (hoist_speculative(code)) analyze_frame_constants_once(code);
+    if (hoist_native_calls(code)) analyze_frame_constants_once(code);
 }
 
 static void analyze_frame_constants_once(FilterCode &code) {

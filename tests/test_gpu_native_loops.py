@@ -96,3 +96,52 @@ def test_loop_of_native_calls_through_the_reference_abi():
                                                      got.ctypes.data_as(C.c_void_p))
     assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
     assert np.array_equal(got, want), stats(got, want)
+
+
+# ---- native calls with frame-constant arguments under pixel-dependent control ----
+# The reference runs such a call when the first pixel reaches it and finds the result in its cache afterwards
+# (native-filters/cache.c:110-147); here the call moves in front of the outermost pixel-dependent statement around it
+# (passes.cpp hoist_native_calls) and runs once per frame.
+SPLIT = """
+filter split (image in, float s: 0-1 (0.02), int mode: 0-1 (1))
+  if mode > 0 then
+    if x > 0 then
+      b = gaussian_blur(in, s, s * 2); b(xy)
+    else
+      if y > t - 0.5 then c = gaussian_blur(in, s * 3, s); rr = render(in); c(xy) * 0.5 + rr(xy * 0.9) * 0.5 else in(xy) end
+    end
+  else
+    in(xy * 0.5)
+  end
+end
+"""
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_native_calls_under_pixel_dependent_conditionals(mode):
+    w, h = 160, 96
+    img = F.synthetic_image(w, h, seed=9)
+    flt, inv = make_invocation(SPLIT, w, h, {"mode": mode}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for t in (0.25, 0.75):
+        got = inv.render(t=t)
+        want = cf.render(w, h, uservals={"mode": mode}, images={"in": img}, t=t)
+        assert np.array_equal(got, want), (mode, t, stats(got, want))
+
+
+def test_native_calls_under_pixel_dependent_conditionals_through_the_reference_abi():
+    from mathmap_amd._lib import selftest_lib
+    w, h = 160, 96
+    img = np.ascontiguousarray(F.synthetic_image(w, h, seed=9))
+    _, inv = make_invocation(SPLIT, w, h, {}, {"in": img})
+    want = inv.render(t=0.25)
+    got = np.zeros((h, w, 4), np.uint8)
+    rc = selftest_lib().mmhip_selftest_abi_roundtrip(SPLIT.encode(), 1, img.ctypes.data_as(C.c_void_p), w, h, 3, w, h, 0.25, 2,
+                                                     got.ctypes.data_as(C.c_void_p))
+    assert rc == 0, selftest_lib().mmhip_selftest_error().decode()
+    assert np.array_equal(got, want), stats(got, want)
+
+
+def test_pixel_dependent_arguments_are_still_refused():
+    with pytest.raises(mm.MathMapError, match="pixel-dependent arguments"):
+        mm.Filter("filter f (image in) b = gaussian_blur(in, 0.01 + abs(x) * 0.01, 0.01); b(xy) end")
