@@ -105,7 +105,7 @@ class Workload:
             self.inv.set(k, v)
         self.jit_seconds = time.perf_counter() - t0
         self.out = torch.empty((size, size, 4), dtype=torch.uint8, device="cuda")
-        self.inv.enable_timing(True)
+        self.inv.enable_timing(False)     # per-launch event pairs only in per_launch_pass (they cost 7 us per frame)
 
     def render(self, frame, stream, rows=None, out=None):
         """Frame `frame` of the animation: t = frame / 120 and the frame number itself, as the command line passes
@@ -177,20 +177,48 @@ class Workload:
             return None
 
 
-def timed_frames(torch, wl, steps, warmup, stream, first_frame=0):
-    """W untimed + K timed frames queued back to back; returns (elapsed_s, mean kernel ms)."""
+PER_LAUNCH_PASS_FRAMES = 40
+KERNEL_MS_NOTE = ("kernel_ms: GPU time per step over the timed region, from one HIP event before its first and one behind its "
+                  "last launch on the launch stream (back-to-back launches overlap at their edges, so this can be below the "
+                  "isolated duration); kernel_ms_per_launch_events / kernel_ms_per_kernel: an untimed pass right after it with "
+                  "an event pair around every launch -- the figures rocprofv3's kernel trace is compared with")
+
+
+def per_launch_pass(torch, wl, render_one, frames):
+    """Untimed: `frames` more frames with one HIP event pair around every kernel launch (on the launch stream), for the
+    per-kernel figures rocprofv3's kernel trace is compared with.  The pairs themselves cost 7 us per frame on the
+    headline kernel (tools/event_overhead.py: 0.207 ms per frame with them, 0.200 without), which is why the timed
+    region carries two events, not two per launch.  Returns (mean pixel-kernel ms, [(native kernel label, ms)])."""
     import numpy as np
+    settle_clocks(torch, render_one, 60.0, batch=4)      # it follows CPU work (the verification): the clocks have dropped
+    wl.inv.enable_timing(True)
+    wl.inv.drain_kernel_ms()
+    wl.inv.drain_native_kernel_ms()
+    for i in range(frames):
+        render_one(i)
+    torch.cuda.synchronize()
+    ms = wl.inv.drain_kernel_ms()
+    native = wl.inv.drain_native_kernel_ms()
+    wl.inv.enable_timing(False)
+    return (float(np.mean(ms)) if ms else None), native
+
+
+def timed_frames(torch, wl, steps, warmup, stream, first_frame=0):
+    """W untimed + K timed frames queued back to back, one HIP event before the first and one behind the last launch
+    (torch's current stream is the launch stream); returns (elapsed_s, GPU ms per frame over the timed region)."""
+    wl.inv.enable_timing(False)
     for i in range(warmup):
         wl.render(first_frame + i, stream)
     torch.cuda.synchronize()
-    wl.inv.drain_kernel_ms()
-    wl.inv.drain_native_kernel_ms()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for i in range(steps):
         wl.render(first_frame + i, stream)
+    e1.record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return el, float(np.mean(wl.inv.drain_kernel_ms()))
+    return el, e0.elapsed_time(e1) / steps
 
 
 def settle_clocks(torch, render_one, target_ms, batch=16, cap_frames=2000):
@@ -369,7 +397,11 @@ def sub_record(torch, mm, F, name, size, uv, args, stream, cores, frames, warmup
     # the same clock-settle phase as the headline workload (a handful of timed frames is a few milliseconds of GPU work)
     settle_clocks(torch, lambda i: d.render(first_frame + i, stream), min(args.settle_ms, 100.0), batch=4 if name == "gauss" else 16)
     el, kms = timed_frames(torch, d, frames, warmup, stream, first_frame)
-    native = d.inv.drain_native_kernel_ms()
+    if host_img is None and d.needs_image:
+        host_img = d.host_images()
+    last = first_frame + frames - 1          # what d.out holds after the timed frames
+    vs = [d.verify(last, images=host_img)]
+    launch_ms, native = per_launch_pass(torch, d, lambda i: d.render(first_frame + i, stream), min(frames, PER_LAUNCH_PASS_FRAMES))
     bpp = ALGO_BYTES_PER_PIXEL[name]
     px = size * size
     ent = {"workload": "%s %dx%d, %s" % (NAMES[name], size, size, "-D" + " -D".join("%s=%g" % kv for kv in sorted(uv.items())) if uv else "defaults"),
@@ -380,9 +412,11 @@ def sub_record(torch, mm, F, name, size, uv, args, stream, cores, frames, warmup
         for label, ms in native:
             per.setdefault(label, []).append(ms)
         per = {k: float(np.mean(v)) for k, v in per.items()}
-        kms = float(sum(per.values()))
         ent["kernel_ms_per_kernel"] = per
+        ent["kernel_ms_per_kernel_sum"] = float(sum(per.values()))
     ent["kernel_ms"] = kms
+    ent["kernel_ms_per_launch_events"] = launch_ms
+    ent["kernel_ms_note"] = KERNEL_MS_NOTE
     ach = px * bpp / (kms * 1e-3) / 1e9
     tr, trs = pmc_traffic(pmc_name, size, d.kernel_key())
     roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -409,14 +443,9 @@ def sub_record(torch, mm, F, name, size, uv, args, stream, cores, frames, warmup
                         "pow chain, ~670 wave-instructions per pixel: profiles/*sq_counters_droste*), the HBM fraction is what "
                         "that leaves of the memory system")
     ent["roofline"] = roof
-    if host_img is None and d.needs_image:
-        host_img = d.host_images()
-    vs = []
-    last = first_frame + frames - 1          # what d.out holds after the timed frames
-    for fr in [last] + sorted(set(verify_frames or []) - {last}):
-        if fr != last:
-            d.render(fr, stream)
-            torch.cuda.synchronize()
+    for fr in sorted(set(verify_frames or []) - {last}):
+        d.render(fr, stream)
+        torch.cuda.synchronize()
         vs.append(d.verify(fr, images=host_img))
     ent["verified"] = all(v["ok"] for v in vs)
     ent["verification"] = vs if len(vs) > 1 else vs[0]
@@ -522,19 +551,19 @@ def main():
         step(i)
     torch.cuda.synchronize()
     settle_ms, settle_frames = settle_clocks(torch, step, args.settle_ms)
-    wl.inv.drain_kernel_ms()                     # forget the warm-up launches' event pairs
-    wl.inv.drain_native_kernel_ms()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e0.record()                                  # HIP events on the launch stream (torch's current one) around the region
     for i in range(args.steps):
         step(i)                                  # queued back to back: no synchronisation per step
+    e1.record()
     torch.cuda.synchronize()
     comm.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    my_kernel_ms = float(np.mean(wl.inv.drain_kernel_ms()))   # HIP events on the launch stream around every launch
-    native = wl.inv.drain_native_kernel_ms()
+    my_kernel_ms = e0.elapsed_time(e1) / args.steps     # GPU time per step over the timed region
     elapsed = comm.max(elapsed)
     per_rank_ms = comm.gather(my_kernel_ms)
 
@@ -562,6 +591,8 @@ def main():
         hpx_all = comm.sum(hpx)
         hsame_all = comm.sum(0.0 if hsame else 1.0) == 0.0
 
+    # (behind the verification: that one looks at the frame the timed region left in the output buffer)
+    launch_ms, native = per_launch_pass(torch, wl, step, min(args.steps, PER_LAUNCH_PASS_FRAMES))
     if rank == 0:
         mpix = w * h * args.steps * (1 if stripes else world) / 1e6
         value = mpix / elapsed
@@ -572,7 +603,6 @@ def main():
             for label, ms in native:
                 per.setdefault(label, []).append(ms)
             per_kernel = {k: float(np.mean(v)) for k, v in per.items()}
-            k_ms = float(sum(per_kernel.values())) if per_kernel else elapsed / args.steps * 1e3
         bpp = ALGO_BYTES_PER_PIXEL[args.workload]
         px_per_launch = w * (row_hi - row_lo)
         hbm_achieved = px_per_launch * bpp / (k_ms * 1e-3) / 1e9
@@ -614,10 +644,11 @@ def main():
                                        "(half of the 157.3 TF vector peak) is not available to it",
                                "pixel_iterations_per_launch": n_iter, "useful_flops_per_launch": flops,
                                "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "kernel_ms": k_ms,
-                               "hbm": hbm}
+                               "kernel_ms_per_launch_events": launch_ms, "kernel_ms_note": KERNEL_MS_NOTE, "hbm": hbm}
         else:
             res["roofline"] = dict(hbm, bound="valu" if args.workload == "droste" else "hbm", traffic=traffic,
-                                   traffic_source=traffic_src, kernel=kernel_name, kernel_ms=k_ms)
+                                   traffic_source=traffic_src, kernel=kernel_name, kernel_ms=k_ms,
+                                   kernel_ms_per_launch_events=launch_ms, kernel_ms_note=KERNEL_MS_NOTE)
             if args.workload == "gauss":
                 floor = px_per_launch * GAUSS_FUSED_FLOOR_BYTES / (k_ms * 1e-3) / 1e9
                 ops = GAUSS_F64_OPS_PER_PIXEL
@@ -656,6 +687,7 @@ def main():
                 # the generic kernel (user values read at run time) on the same frame: must be byte-identical
                 g = Workload(mm, F, torch, args.workload, size, uv, False, args.tile_w, dev_img=wl.dev_img)
                 gms = []
+                g.inv.enable_timing(True)
                 for i in range(3):
                     g.render(last_frame, stream)
                     gms.append(g.inv.last_kernel_ms())
