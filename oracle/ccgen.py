@@ -396,8 +396,11 @@ class _ImageDesc(C.Structure):
                 ("middle_y", C.c_float), ("ax", C.c_float), ("bx", C.c_float), ("ay", C.c_float), ("by", C.c_float)]
 
 
+MEMO_EXTRA = 32
+
+
 class _Memo(C.Structure):
-    _fields_ = [("valid", C.c_int), ("func", C.c_int), ("in_idx", C.c_int), ("a1", C.c_float), ("a2", C.c_float),
+    _fields_ = [("valid", C.c_int), ("func", C.c_int), ("in_idx", C.c_int), ("in2_idx", C.c_int), ("a1", C.c_float), ("a2", C.c_float),
                 ("map", C.c_void_p), ("w", C.c_int), ("h", C.c_int)]
 
 
@@ -415,7 +418,8 @@ class _Args(C.Structure):
                 ("edge_behaviour_x", C.c_int), ("edge_behaviour_y", C.c_int), ("edge_color_x", C.c_uint),
                 ("edge_color_y", C.c_uint), ("uservals", C.POINTER(_Userval)), ("images", C.POINTER(_ImageDesc)),
                 ("num_images", C.c_int), ("native_slot_base", C.c_int), ("memo", C.POINTER(_Memo)),
-                ("curves", C.c_void_p), ("gradients", C.c_void_p), ("closure_base", C.c_int), ("pixel_inc", C.c_int)]
+                ("curves", C.c_void_p), ("gradients", C.c_void_p), ("closure_base", C.c_int), ("pixel_inc", C.c_int),
+                ("memo_sites", C.c_int), ("memo_cap", C.c_int)]
 
 
 def _run(cmd):
@@ -580,7 +584,10 @@ class CpuFilter:
             else:
                 uv[i].i = 0
         nbase = len(descs)
-        for _ in range(self.nnative):
+        # one result slot per native call site, and room for the further argument sets of sites that run more than once
+        # per frame (mm_oracle_rt.c mmo_memo_slot)
+        nmemo = self.nnative + MEMO_EXTRA if self.nnative else 0
+        for _ in range(nmemo):
             d = _ImageDesc()
             d.kind = 2
             descs.append(d)
@@ -605,7 +612,7 @@ class CpuFilter:
             d.kind = 2
             descs.append(d)
         dtab = (_ImageDesc * len(descs))(*descs)
-        memo = (_Memo * max(self.nnative, 1))()
+        memo = (_Memo * max(nmemo, 1))()
         a = _Args()
         # `render_size`: a render of the (width x height) canvas at another pixel size -- the GIMP
         # preview (mathmap.c:2191-2223): img_width/height stay, render_width/height change
@@ -629,6 +636,7 @@ class CpuFilter:
         a.curves, a.gradients = ctab.ctypes.data, gtab.ctypes.data
         a.closure_base = closure_base
         a.pixel_inc = pixel_inc
+        a.memo_sites, a.memo_cap = self.nnative, nmemo
         out = np.zeros((height, rw, 4), np.float32) if floatmap else np.zeros((height, rw, bpp), np.uint8)
         xy = C.create_string_buffer(max(self.lib.mmo_xy_size(), 16))
         r0, r1 = rows if rows is not None else (0, height)
@@ -652,7 +660,7 @@ class CpuFilter:
                 th.join()
         if timing is not None:
             timing.append(time.perf_counter() - t0)
-        self.lib.mmo_free_memo(C.byref(a), self.nnative)
+        self.lib.mmo_free_memo(C.byref(a), nmemo)
         del keep
         return out
 

@@ -89,6 +89,8 @@ typedef struct {
     const color_t *gradients;
     int closure_base;            /* image-table slot of closure image #0 rendered for native filters, or -1 */
     int pixel_inc;               /* drawable_get_pixel_inc (mathmap.c:1320-1327): fast_image_source_scale while previewing, else 1 (0 = 1) */
+    int memo_sites, memo_cap;    /* memo[0 .. memo_sites): one entry per native call site; [memo_sites .. memo_cap): further argument
+                                    sets of sites that run more than once per frame (mmo_memo_slot) */
 } mmo_args;
 
 /* ---- op macros (opmacros.h) ---- */
@@ -180,6 +182,7 @@ mmo_image mmo_native_convolve(const mmo_args *A, int slot, mmo_image in, mmo_ima
 mmo_image mmo_native_half_convolve(const mmo_args *A, int slot, mmo_image in, mmo_image filter, float copy_alpha);
 mmo_image mmo_native_visualize_fft(const mmo_args *A, int slot, mmo_image in, float ignore_alpha);
 mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h);
+int mmo_memo_slot(const mmo_args *A, int site, int func, int in, int in2, float a1, float a2);
 void mmo_render_image(const mmo_args *A, const mmo_image_desc *src, mmo_image srcv, int w, int h, float *out);
 void mmo_gauss_iir(float *map, int width, int height, float hdev, float vdev);
 void mmo_gauss_rle(float *map, int width, int height, float hdev, float vdev);

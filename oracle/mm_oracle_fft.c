@@ -180,7 +180,7 @@ static void memo_map(mmo_native_memo *m, int w, int h) {
 /* convolve.c:67-174 */
 mmo_image mmo_native_convolve(const mmo_args *A, int slot, mmo_image in, mmo_image filter, float normalize_f,
                               float copy_alpha_f) {
-    mmo_native_memo *m = &A->memo[slot];
+    mmo_native_memo *m = &A->memo[slot = mmo_memo_slot(A, slot, 3, in.idx, filter.idx, normalize_f, copy_alpha_f)];
     const int normalize = normalize_f != 0.0, copy_alpha = copy_alpha_f != 0.0;
     int w = A->render_width, h = A->render_height;
     if (A->images[in.idx].kind == MMO_IMG_FLOATMAP) {
@@ -228,7 +228,7 @@ mmo_image mmo_native_convolve(const mmo_args *A, int slot, mmo_image in, mmo_ima
 
 /* convolve.c:176-272 */
 mmo_image mmo_native_half_convolve(const mmo_args *A, int slot, mmo_image in, mmo_image filter, float copy_alpha_f) {
-    mmo_native_memo *m = &A->memo[slot];
+    mmo_native_memo *m = &A->memo[slot = mmo_memo_slot(A, slot, 4, in.idx, filter.idx, copy_alpha_f, 0.0f)];
     const int copy_alpha = copy_alpha_f != 0.0;
     int w = A->render_width, h = A->render_height;
     if (A->images[in.idx].kind == MMO_IMG_FLOATMAP) {
@@ -270,7 +270,7 @@ mmo_image mmo_native_half_convolve(const mmo_args *A, int slot, mmo_image in, mm
 
 /* convolve.c:274-357 */
 mmo_image mmo_native_visualize_fft(const mmo_args *A, int slot, mmo_image in, float ignore_alpha_f) {
-    mmo_native_memo *m = &A->memo[slot];
+    mmo_native_memo *m = &A->memo[slot = mmo_memo_slot(A, slot, 5, in.idx, -1, ignore_alpha_f, 0.0f)];
     const int ignore_alpha = ignore_alpha_f != 0.0;
     int w = A->render_width, h = A->render_height;
     if (A->images[in.idx].kind == MMO_IMG_FLOATMAP) {

@@ -431,10 +431,27 @@ void mmo_gauss_rows_horizontal(float *vmid, int width, int height, int nrows, fl
     free(val_p); free(val_m); free(src); free(dest);
 }
 
+/* The reference caches native-filter results per invocation under (filter, arguments) (native-filters/cache.c:110-156): every
+ * distinct argument set has an image of its own, whichever call site asked.  Here: entry `site` for the first argument set a
+ * call site sees; a site that runs again with other arguments (inside a loop -- each pixel runs the loop anew) finds or takes
+ * one of the entries behind the sites'.  Returns the entry (= its image slot behind native_slot_base). */
+int mmo_memo_slot(const mmo_args *A, int site, int func, int in, int in2, float a1, float a2) {
+    int i;
+    for (i = 0; i < A->memo_cap; ++i) {
+        const mmo_native_memo *m = &A->memo[i];
+        if (m->valid && m->func == func && m->in_idx == in && m->in2_idx == in2 && m->a1 == a1 && m->a2 == a2) return i;
+    }
+    if (A->memo_cap <= A->memo_sites || !A->memo[site].valid) return site;
+    for (i = A->memo_sites; i < A->memo_cap; ++i)
+        if (!A->memo[i].valid) return i;
+    fprintf(stderr, "mm_oracle: more than %d native-filter results in one frame\n", A->memo_cap);
+    abort();
+}
+
 /* native_filter_gaussian_blur, gauss.c:641-670, with the per-invocation memo of
  * native-filters/cache.c:110-156 (keyed by input image and the two float args). */
 mmo_image mmo_native_gaussian_blur(const mmo_args *A, int slot, mmo_image in, float hdev, float vdev) {
-    mmo_native_memo *m = &A->memo[slot];
+    mmo_native_memo *m = &A->memo[slot = mmo_memo_slot(A, slot, 1, in.idx, 0, hdev, vdev)];
     mmo_image_desc *dst = &A->images[A->native_slot_base + slot];
     mmo_image out;
     int w = A->render_width, h = A->render_height;
@@ -461,6 +478,7 @@ mmo_image mmo_native_gaussian_blur(const mmo_args *A, int slot, mmo_image in, fl
         m->valid = 1;
         m->func = 1;
         m->in_idx = in.idx;
+        m->in2_idx = 0;
         m->a1 = hdev;
         m->a2 = vdev;
         m->w = w;
@@ -476,10 +494,13 @@ mmo_image mmo_native_gaussian_blur(const mmo_args *A, int slot, mmo_image in, fl
 
 /* RENDER op on a drawable (builtins.c:267-346, force = 0) */
 mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h) {
-    mmo_native_memo *m = &A->memo[slot];
-    mmo_image_desc *dst = &A->images[A->native_slot_base + slot];
+    mmo_native_memo *m;
+    mmo_image_desc *dst;
     mmo_image out;
     const mmo_image_desc *src = &A->images[in.idx];
+    if (src->kind != MMO_IMG_FLOATMAP) slot = mmo_memo_slot(A, slot, 2, in.idx, 0, 0.0f, 0.0f);
+    m = &A->memo[slot];
+    dst = &A->images[A->native_slot_base + slot];
     if (src->kind == MMO_IMG_FLOATMAP) {
         /* a closure the harness rendered beforehand: render_image made a new, plain float map of it
          * (no resize wrapper on the result, builtins.c:270-271,345) */
@@ -501,6 +522,8 @@ mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h) {
         m->valid = 1;
         m->func = 2;
         m->in_idx = in.idx;
+        m->in2_idx = 0;
+        m->a1 = m->a2 = 0.0f;
         m->w = w;
         m->h = h;
     }

@@ -773,3 +773,28 @@ def test_oracle_strided_bilinear_fetch_against_a_numpy_restatement(inc):
             want = (want << 8) | (int(np.rint(acc)) & 0xff)
         got = fn(C.byref(a), float(x), float(-y), C.byref(d), 0)
         assert got == want, (inc, float(x), float(y), hex(got), hex(want))
+
+
+def test_oracle_native_results_are_cached_per_argument_set():
+    """A native call site inside a loop runs once per iteration -- and, in the oracle, once per iteration *per pixel*.
+    The reference caches results per invocation under (filter, arguments) (native-filters/cache.c:110-156); the oracle's
+    memo must do the same: the loop equals the chain written out, results of earlier iterations stay readable, and the
+    frame takes milliseconds (one entry per call site recomputed every blur for every pixel: minutes)."""
+    import time
+    import mathmap_amd as mm
+    from oracle.ccgen import CpuFilter
+    loop = """filter keep (image in, float s: 0-1 (0.02))
+      img = in; prev = in; i = 0;
+      while i < 3 do prev = img; img = gaussian_blur(img, s * (i + 1), s); i = i + 1 end;
+      prev(xy) * 0.5 + img(xy) * 0.5
+    end"""
+    flat = ("filter u (image in, float s: 0-1 (0.02)) p = gaussian_blur(in, s, s); q = gaussian_blur(p, s * 2, s); "
+            "w = gaussian_blur(q, s * 3, s); q(xy) * 0.5 + w(xy) * 0.5 end")
+    w, h = 96, 64
+    img = F.synthetic_image(w, h, seed=11)
+    t0 = time.time()
+    a = CpuFilter(mm.Filter(loop).ir_json_raw).render(w, h, images={"in": img})
+    assert time.time() - t0 < 20
+    b = CpuFilter(mm.Filter(flat).ir_json_raw).render(w, h, images={"in": img})
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, CpuFilter(mm.Filter("filter i (image in) in(xy) end").ir_json_raw).render(w, h, images={"in": img}))

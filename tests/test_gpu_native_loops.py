@@ -145,3 +145,27 @@ def test_native_calls_under_pixel_dependent_conditionals_through_the_reference_a
 def test_pixel_dependent_arguments_are_still_refused():
     with pytest.raises(mm.MathMapError, match="pixel-dependent arguments"):
         mm.Filter("filter f (image in) b = gaussian_blur(in, 0.01 + abs(x) * 0.01, 0.01); b(xy) end")
+
+
+# every call of an in-loop site has a result of its own: the last one and the one before it are both still readable
+# behind the loop (the reference caches per argument set, native-filters/cache.c:110-156)
+KEEP = """
+filter keep (image in, float s: 0-1 (0.02))
+  img = in; prev = in; i = 0;
+  while i < 3 do prev = img; img = gaussian_blur(img, s * (i + 1), s); i = i + 1 end;
+  prev(xy) * 0.5 + img(xy) * 0.5
+end
+"""
+KEEP_UNROLLED = ("filter u (image in, float s: 0-1 (0.02)) p = gaussian_blur(in, s, s); q = gaussian_blur(p, s * 2, s); "
+                 "w = gaussian_blur(q, s * 3, s); q(xy) * 0.5 + w(xy) * 0.5 end")
+
+
+def test_results_of_earlier_iterations_stay_readable():
+    w, h = 160, 96
+    img = F.synthetic_image(w, h, seed=11)
+    flt, inv = make_invocation(KEEP, w, h, {}, {"in": img})
+    got = inv.render(t=0.25)
+    want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, t=0.25)
+    assert np.array_equal(got, want), stats(got, want)
+    _, ui = make_invocation(KEEP_UNROLLED, w, h, {}, {"in": img})
+    assert np.array_equal(got, ui.render(t=0.25))
