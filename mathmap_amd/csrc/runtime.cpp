@@ -934,6 +934,25 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         inv->native_rows[k] = {got_lo, got_hi};
         table_changed = true;
     }
+    // dynamic entries this frame did not use (the loop ran fewer times than before): their maps go back (a map is
+    // 16 B per pixel of the frame; sixteen of them at 16384^2 are 69 GB)
+    if (f->ks.native_sites < (int)f->ks.natives.size()) {
+        std::vector<char> used(f->ks.natives.size(), 0);
+        for (const RecordedCall &call : calls) used[call.k] = 1;
+        for (size_t k = (size_t)f->ks.native_sites; k < f->ks.natives.size(); ++k) {
+            if (used[k] || !inv->native_maps[k]) continue;
+            HIP_TRY(hipStreamSynchronize(s));
+            (void)hipFree(inv->native_maps[k]);
+            inv->native_maps[k] = nullptr;
+            inv->native_memo_gen[k] = ~0ULL;
+            inv->native_seen_gen[k] = ~0ULL;
+            inv->native_rows[k] = {0, 0};
+            HImageDesc &d = inv->images[inv->native_slot_base + (int)k];
+            d.kind = IMG_NULL;
+            d.data = nullptr;
+            table_changed = true;
+        }
+    }
     if (table_changed) {
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipMemcpy(inv->d_images, inv->images.data(), inv->images.size() * sizeof(HImageDesc), hipMemcpyHostToDevice));
