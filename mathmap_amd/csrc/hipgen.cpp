@@ -50,6 +50,8 @@ struct Generator {
     std::ostringstream out;
     KernelSource ks;
     std::map<Value *, int> transfer_off;       // hoisted values read by the pixel kernel
+    std::map<const Stmt *, int> dual_base_off; // outermost loops of both slices with native calls: where the prologue leaves the
+                                               // number of dynamic entries taken before the loop
     std::vector<Value *> transfer_order;
     std::map<const Stmt *, int> native_index;
 
@@ -139,7 +141,7 @@ struct Generator {
     // is `v` nameable from code of slice `sl` (defined there, or transferred into it)?
     bool value_visible(const Value *v, Slice sl) const {
         if (v->index < 0) return true;
-        if (sl == PROLOGUE) return v->hoisted;
+        if (sl == PROLOGUE) return v->hoisted || v->loop_const;
         if (sl == ROWS) return v->row_const || transfer_off.count(const_cast<Value *>(v)) > 0;
         return !v->hoisted || transfer_off.count(const_cast<Value *>(v)) > 0;
     }
@@ -165,6 +167,11 @@ struct Generator {
                std::to_string(k) + ", " + std::to_string(ks.native_sites) + ", ";
     }
 
+    // the pixel slice's form of a call the prologue made from inside a loop: the handle of the next dynamic entry
+    std::string native_result_in_loop() const {
+        return "mm_native_result_in_loop(A, mm_dyn_ctr, " + std::to_string(ks.native_sites) + ")";
+    }
+
     std::string rhs(const Rhs &r, Slice sl, const Stmt *stmt, const CompVar *lhs) {
         switch (r.kind) {
             case Rhs::Prim: return prim(r.prim, sl);
@@ -179,6 +186,8 @@ struct Generator {
                 if (r.filter->kind == Filter::MathMap)      // index -2 - id: rendered for a native filter by the runtime
                     return "mm_closure_image(A, " + std::to_string(stmt ? stmt->closure_id : -1) + ")";
                 auto it = native_index.find(stmt);
+                if (it != native_index.end() && sl == PIXEL && stmt->hoisted && ks.natives[it->second].in_loop)
+                    return native_result_in_loop();      // a loop in both slices (passes.cpp mark_dual_loops): the prologue made this call
                 if (it == native_index.end() || sl != PROLOGUE)
                     throw CompileError("native filter `" + r.filter->name +
                                        "' is called with pixel-dependent arguments; the HIP backend needs them frame-constant");
@@ -210,6 +219,8 @@ struct Generator {
                 const char *cn = r.op->cname;
                 if (!strcmp(cn, "RENDER")) {
                     auto it = native_index.find(stmt);
+                    if (it != native_index.end() && sl == PIXEL && stmt->hoisted && ks.natives[it->second].in_loop)
+                        return native_result_in_loop();
                     if (it == native_index.end() || sl != PROLOGUE)
                         throw CompileError("render() needs frame-constant arguments in the HIP backend");
                     int k = it->second;
@@ -962,23 +973,34 @@ struct Generator {
                     phis(s->phis, 1, sl, ind + "  ");
                     out << ind << "}\n";
                     break;
-                case Stmt::While:
+                case Stmt::While: {
+                    // a loop of both slices whose calls the prologue numbers: the pixel slice starts counting where the
+                    // prologue stood when it entered the loop
+                    auto db = dual_base_off.find(s);
+                    if (db != dual_base_off.end() && sl == PROLOGUE)
+                        out << ind << "*(int *)(XY + " << db->second << ") = ((const int *)(XY + " << ks.native_ctr_offset << "))[1];\n";
+                    if (db != dual_base_off.end() && sl == PIXEL)
+                        out << ind << "mm_dyn_ctr = *(const int *)(XY + " << db->second << ");\n";
                     phis(s->phis, 0, sl, ind);
                     out << ind << "while (" << rhs(s->cond, sl, s, nullptr) << ") {\n";
                     stmts(s->body, sl, ind + "  ");
                     phis(s->phis, 1, sl, ind + "  ");
                     out << ind << "}\n";
                     break;
+                }
                 default: break;
             }
         }
     }
 
-    void decls(const std::vector<Value *> &defs, const std::string &ind) {
+    // `null_images`: image handles start as the null image -- in the prologue, whose every transferred value is stored at
+    // the end whether or not the branch that assigns it ran (the pixel kernel loads the descriptors of transferred images
+    // up front)
+    void decls(const std::vector<Value *> &defs, const std::string &ind, bool null_images = false) {
         std::set<Value *> seen;
         for (Value *v : defs) {
             if (v->index < 0 || !seen.insert(v).second) continue;
-            out << ind << ctype(v->var) << " " << vname(v) << ";\n";
+            out << ind << ctype(v->var) << " " << vname(v) << (null_images && v->var->type == Ty::Image ? " = mm_null_image()" : "") << ";\n";
         }
     }
 
@@ -1178,6 +1200,21 @@ struct Generator {
             transfer_order.push_back(v);
             off += sz;
         }
+        {
+            std::function<void(Block &)> find_dual = [&](Block &b) {
+                for (Stmt *s : b) {
+                    if (s->kind == Stmt::If) { find_dual(s->then_); find_dual(s->else_); }
+                    if (s->kind != Stmt::While) continue;
+                    if (s->hoisted && s->in_pixel) {        // outermost: loops inside it go on counting
+                        off = (off + 3) / 4 * 4;
+                        dual_base_off[s] = off;
+                        off += 4;
+                    } else
+                        find_dual(s->body);
+                }
+            };
+            if (ks.native_sites < (int)ks.natives.size()) find_dual(code.body);
+        }
         ks.xy_bytes = (off + 15) / 16 * 16;
         if (ks.xy_bytes == 0) ks.xy_bytes = 16;
         ks.has_prologue = !pro_defs.empty();
@@ -1298,6 +1335,14 @@ MM_DEV mm_image mm_native_call_in_loop(const mm_args &A, char *dyn, int *ctr, in
     const int __renderPixelW = A.render_width, __renderPixelH = A.render_height; \
     (void)t; (void)R; (void)frame; (void)__canvasPixelW; (void)__canvasPixelH; (void)__renderPixelW; (void)__renderPixelH;
 )";
+        if (ks.native_sites < (int)ks.natives.size())      // (only kernels with in-loop native calls: the others' text, and cache keys, stay as they were)
+            out << R"(// The pixel slice's side of a loop that runs in both slices: its n-th call from an in-loop site is the prologue's n-th.
+MM_DEV mm_image mm_native_result_in_loop(const mm_args &A, int &n, int sites) {
+    mm_image im; im.idx = A.native_slot_base + sites + (n < MM_NATIVE_DYN_CALLS ? n : MM_NATIVE_DYN_CALLS - 1); ++n;
+    im.pw = A.render_width; im.ph = A.render_height; im.xf = im.yf = 1.0f; im.resized = 0;
+    return im;
+}
+)";
         emit_functions();
         // ---- prologue ----
         ks.prologue_uses_time = hoisted_uses_time(code.body);
@@ -1309,7 +1354,7 @@ MM_DEV mm_image mm_native_call_in_loop(const mm_args &A, char *dyn, int *ctr, in
                "    if (gid < A.num_rows) A.ytab[gid] = CALC_VIRTUAL_Y(A.first_row + gid, A.frame_render_height, A.sampling_offset_y);\n"
                "    if (gid != 0) return;\n  }\n  MM_INTERNALS\n";
         if (!(fn_root ? fn_root : &code)->functions.empty()) out << "  const int col = 0, rl = 0; unsigned mm_rand_ctr = 0; (void)col; (void)rl; (void)mm_rand_ctr;\n";
-        decls(pro_defs, "  ");
+        decls(pro_defs, "  ", true);
         if (!ks.natives.empty()) {      // no call recorded yet this frame
             for (const NativeCall &nc : ks.natives) out << "  *(int *)(XY + " << nc.record_offset << ") = 0;\n";
             out << "  { int *mm_ctr = (int *)(XY + " << ks.native_ctr_offset << "); mm_ctr[0] = mm_ctr[1] = mm_ctr[2] = mm_ctr[3] = 0; }\n";
@@ -1397,6 +1442,8 @@ MM_DEV mm_image mm_native_call_in_loop(const mm_args &A, char *dyn, int *ctr, in
                    "  const float y = A.ytab[rl];    // CALC_VIRTUAL_Y(first_row + rl, ...), once per row by the prologue\n"
                    "  unsigned mm_rand_ctr = 0;      // RAND call number within this pixel\n"
                    "  (void)y; (void)mm_rand_ctr;\n";
+            if (!dual_base_off.empty())
+                out << "  int mm_dyn_ctr = 0;            // in-loop native calls made so far by this pixel's copy of a loop of both slices\n";
             row_loads("  ", "rl");
             decls(pix_defs, "  ");
             stmts(code.body, PIXEL, "  ");
@@ -1461,6 +1508,8 @@ MM_DEV mm_image mm_native_call_in_loop(const mm_args &A, char *dyn, int *ctr, in
                 << I << "    const int rl = rl_u < A.num_rows ? rl_u : A.num_rows - 1;\n"
                 << I << "    unsigned mm_rand_ctr = 0;      // RAND call number within this pixel\n"
                 << I << "    (void)y; (void)rl; (void)mm_rand_ctr;\n";
+            if (!dual_base_off.empty())
+                out << I << "    int mm_dyn_ctr = 0;            // in-loop native calls made so far by this pixel's copy of a loop of both slices\n";
             row_loads(I + "    ", "rl");
             decls(pix_defs, (I + "    ").c_str());
             stmts(code.body, PIXEL, (I + "    ").c_str());

@@ -70,6 +70,8 @@ struct Value {
     Stmt *def = nullptr;
     unsigned constness = CONST_MAX;
     bool hoisted = false;  // lives in the frame-constant block
+    bool loop_const = false;  // frame constant per iteration of a loop that also holds per-pixel code: defined in both slices
+                              // (passes.cpp mark_dual_loops)
     bool row_const = false;   // depends on the row alone: computed once per row by the rows kernel (hipgen.cpp find_row_slice)
 };
 

@@ -88,7 +88,7 @@ struct mm_args {
     float *xtab;
     float *ytab;
     unsigned tiles_magic;             // workgroup id / tile columns by multiply-high (mm_host_abi.h), 0: divide
-    unsigned pad_;
+    unsigned num_images;              // entries of `images` (a handle beyond it -- a value no path of the frame-constant code assigned -- reads as no image)
     // values that depend on the row alone (the reference's x-const slice, new_template.c.in:251-253), computed once per
     // row of the launch by mm_rows: value k of row r at rowtab[k * num_rows + r] (ints stored as their bit pattern)
     float *rowtab;
@@ -588,7 +588,7 @@ MM_DEV mm_tup<4> mm_floatmap_pixel(const mm_image_desc &d, float x, float y) {
 // this once per work-item, before the pixel loop: after the first store of the loop the
 // compiler may no longer use scalar loads for it.
 MM_DEV mm_image_desc mm_load_desc(const mm_args &A, mm_image img) {
-    if (img.idx < 0) {
+    if ((unsigned)img.idx >= A.num_images) {      // (negative: the null image and closure handles)
         mm_image_desc d;
         d.data = nullptr;
         d.w = d.h = 0;

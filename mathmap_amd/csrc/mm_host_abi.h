@@ -46,7 +46,7 @@ struct HArgs {
     float *xtab;
     float *ytab;
     uint32_t tiles_magic;     // ceil(2^32 / tiles_x) when workgroup id / tiles_x is exact by multiply-high, else 0
-    uint32_t pad_;
+    uint32_t num_images;      // entries of `images`
     float *rowtab;            // per-row values of the launch (mm_rows), [value][row]
 };
 

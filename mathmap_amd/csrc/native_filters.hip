@@ -130,6 +130,26 @@ __global__ void __launch_bounds__(256) k_render_drawable(const uint32_t *__restr
     out[i] = t;
 }
 
+// render_image of a float map behind a resize wrapper (builtins.c:303-343 with ORIG_VAL's float-map branch, 247-265):
+// the new map's pixel at its own unit coordinates, scaled by the wrapper's factors, nearest texel of the source, zeros outside
+__global__ void __launch_bounds__(256) k_render_floatmap(const float4 *__restrict__ src, int sw, int sh, float sax, float sbx, float say,
+                                                         float sby, float xf, float yf, float4 *__restrict__ out, int w, int h) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)w * h) return;
+    const int px = (int)(i % w), py = (int)(i / w);
+    const float ax = (float)((float)(w - 1) / 2.0), bx = ax;
+    const float by = (float)((float)(h - 1) / 2.0);
+    const float ay = (float)(by * -1.0);
+    float x = ((float)px - bx) / ax;
+    float y = ((float)py - by) / ay;
+    x *= xf;
+    y *= yf;
+    const int ix = (int)lrintf(sax * x + sbx), iy = (int)lrintf(say * y + sby);
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (ix >= 0 && ix < sw && iy >= 0 && iy < sh) v = src[(long)iy * sw + ix];
+    out[i] = v;
+}
+
 void render_drawable_impl(const HImageDesc &in, const HImage &img, const NativeEnv &env, float *dst, int w, int h, hipStream_t s) {
     const long n = (long)w * h;
     k_render_drawable<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint32_t *)in.data, in.w, in.h, in.scale_x, in.scale_y,
@@ -989,8 +1009,17 @@ int run_native_filter(const std::string &func, const HNativeRec &rec, const std:
         const HImageDesc &in = images[img.idx];
         const int w = render_w, h = render_h;
         if (in.kind == IMG_FLOATMAP) {
-            if (in.w != w || in.h != h) { *err = "render(): float-map input of a different size"; return -1; }
-            if (hipMemcpyAsync(out_map, in.data, (size_t)w * h * 16, hipMemcpyDeviceToDevice, stream) != hipSuccess) { *err = "render(): copy failed"; return -1; }
+            if (!img.resized) {       // builtins.c:273-274: a plain float map is the result itself (here: its copy)
+                if (in.w != w || in.h != h) { *err = "render(): float-map input of a different size"; return -1; }
+                if (hipMemcpyAsync(out_map, in.data, (size_t)w * h * 16, hipMemcpyDeviceToDevice, stream) != hipSuccess) { *err = "render(): copy failed"; return -1; }
+                return 0;
+            }
+            // behind a resize wrapper -- what filter code hands to render() -- the image is of type IMAGE_RESIZE, not
+            // IMAGE_FLOATMAP: render_image samples it into a new map like it does a drawable
+            if ((const void *)in.data == (const void *)out_map) { *err = "render(): internal: source and result share a map"; return -1; }
+            const long n = (long)w * h;
+            k_render_floatmap<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4 *)in.data, in.w, in.h, in.ax, in.bx, in.ay, in.by,
+                                                                            img.xf, img.yf, (float4 *)out_map, w, h);
             return 0;
         }
         if (in.kind != IMG_DRAWABLE) { *err = "render(): input image is not bound"; return -1; }

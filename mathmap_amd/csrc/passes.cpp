@@ -346,6 +346,92 @@ bool internal_is_frame_const(const std::string &n) { return n != "x" && n != "y"
 // statements are assigned to the prologue slice, the pixel slice, or both
 // (control statements whose bodies contain work of both kinds).
 static void analyze_frame_constants_once(FilterCode &code);
+static bool is_native_call(const Stmt *s);
+
+// A loop that holds per-pixel code runs per pixel as a whole (below) -- but a native filter called in it has to be run by
+// the host, from the frame-constant slice:
+//     while i < n do img = gaussian_blur(img, s, s); acc = acc + img(xy) * 0.3; i = i + 1 end
+// Such a loop is emitted in both slices.  Its *loop-constant* part -- statements resting on literals, frame constants from
+// outside, and each other, under control that does likewise; the native calls among them -- runs in the prologue too,
+// where the calls are numbered and recorded as they are made (hipgen.cpp mm_native_call_in_loop); the pixel slice runs the
+// whole loop and, making the same calls in the same order (the control around them is loop-constant), takes the n-th
+// call's result for its n-th call.  Marks: Stmt::hoisted and Stmt::in_pixel both set, Value::loop_const.
+static void mark_dual_loops(FilterCode &code) {
+    std::set<const Value *> was;
+    for (Value &v : code.values) { if (v.loop_const) was.insert(&v); v.loop_const = false; }
+    auto outside_ok = [&](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted || was.count(p.value); };
+    std::function<void(Block &, bool)> visit = [&](Block &b, bool ctx_const) {
+        for (Stmt *top : b) {
+            if (top->kind == Stmt::If) {
+                bool c = ctx_const;
+                if (top->cond.kind == Rhs::Prim) c = c && outside_ok(top->cond.prim);
+                else if (top->cond.kind == Rhs::Internal) c = c && internal_is_frame_const(top->cond.internal);
+                else for (const Primary &p : top->cond.args) c = c && outside_ok(p);
+                visit(top->then_, c);
+                visit(top->else_, c);
+                continue;
+            }
+            if (top->kind != Stmt::While || !ctx_const || top->hoisted || !top->in_pixel) continue;      // outermost per-pixel loops under frame-constant control
+            // candidates: every assignment and phi of the loop, with the control statements around each (inside the loop)
+            std::map<Stmt *, std::vector<Stmt *>> control;      // statement -> enclosing control statements, `top' first
+            std::vector<Stmt *> order;
+            bool has_native = false;
+            std::vector<Stmt *> stack{top};
+            std::function<void(Block &)> gather = [&](Block &bb) {
+                for (Stmt *s : bb) {
+                    if (s->kind == Stmt::Assign || s->kind == Stmt::Phi) { control[s] = stack; order.push_back(s); has_native = has_native || is_native_call(s); }
+                    if (s->kind == Stmt::If) { stack.push_back(s); gather(s->then_); gather(s->else_); gather(s->phis); stack.pop_back(); }
+                    if (s->kind == Stmt::While) { stack.push_back(s); gather(s->phis); gather(s->body); stack.pop_back(); }
+                }
+            };
+            gather(top->phis);
+            gather(top->body);
+            if (!has_native) continue;
+            std::set<const Stmt *> in;
+            for (Stmt *s : order) in.insert(s);
+            auto operand_ok = [&](const Primary &p) {
+                if (p.kind != Primary::Val || p.value->index < 0) return true;
+                if (p.value->def && control.count(p.value->def)) return in.count(p.value->def) != 0;      // defined in this loop
+                return p.value->hoisted || p.value->loop_const || was.count(p.value) != 0;      // (an earlier loop's, this run or the last)
+            };
+            auto rhs_ok = [&](const Rhs &r) {
+                if (r.kind == Rhs::Prim) return operand_ok(r.prim);
+                if (r.kind == Rhs::Internal) return internal_is_frame_const(r.internal);
+                for (const Primary &p : r.args)
+                    if (!operand_ok(p)) return false;
+                return true;
+            };
+            auto stmt_ok = [&](Stmt *s) {
+                if (s->kind == Stmt::Phi) { if (!rhs_ok(s->rhs) || !rhs_ok(s->rhs2)) return false; }
+                else {
+                    const Rhs &r = s->rhs;
+                    const bool kind_ok = r.kind == Rhs::Prim || r.kind == Rhs::Tuple || r.kind == Rhs::Internal || is_native_call(s) ||
+                                         (r.kind == Rhs::Op && r.op->pure && strcmp(r.op->cname, "ORIG_VAL"));
+                    if (!kind_ok || !rhs_ok(r)) return false;
+                }
+                for (Stmt *c : control[s])
+                    if (!rhs_ok(c->cond) || (c->cond.kind == Rhs::Op && !c->cond.op->pure)) return false;
+                return true;
+            };
+            for (bool again = true; again;) {
+                again = false;
+                for (Stmt *s : order)
+                    if (in.count(s) && !stmt_ok(s)) { in.erase(s); again = true; }
+            }
+            bool keeps_native = false;
+            for (Stmt *s : order) keeps_native = keeps_native || (in.count(s) && is_native_call(s));
+            if (!keeps_native) continue;
+            for (Stmt *s : order) {
+                if (!in.count(s)) continue;
+                s->hoisted = true;
+                s->lhs->loop_const = true;
+                for (Stmt *c : control[s]) c->hoisted = true;
+            }
+            for (Stmt *a = top->parent; a; a = a->parent) a->hoisted = true;
+        }
+    };
+    visit(code.body, true);
+}
 
 // Speculative hoisting: a pure library call (cexpf, sin, pow ...) whose operands are literals or
 // frame constants is itself a frame constant even when it sits inside pixel-dependent control
@@ -418,7 +504,7 @@ static bool is_native_call(const Stmt *s) {
 }
 
 static bool hoist_native_calls(FilterCode &code) {
-    auto prim_const = [](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted; };
+    auto prim_const = [](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted || p.value->loop_const; };
     auto cond_const = [&](const Stmt *c) {
         if (c->cond.kind == Rhs::Prim) return prim_const(c->cond.prim);
         if (c->cond.kind == Rhs::Internal) return internal_is_frame_const(c->cond.internal);
@@ -470,7 +556,7 @@ static bool hoist_native_calls(FilterCode &code) {
             for (const Primary &p : ps) {
                 if (p.kind != Primary::Val || p.value->index < 0) continue;
                 if (p.value->def && inside.count(p.value->def)) need(p.value->def);
-                else if (!p.value->hoisted) ok = false;
+                else if (!p.value->hoisted && !p.value->loop_const) ok = false;
                 if (!ok) return;
             }
             order.push_back(s);
@@ -496,26 +582,75 @@ static bool hoist_native_calls(FilterCode &code) {
         }
         auto at = std::find(home->begin(), home->end(), outer);
         if (at == home->end()) throw std::runtime_error("internal: statement not found in its parent's block");
-        for (Stmt *s : order) s->parent = outer->parent;
+        for (Stmt *s : order) {
+            s->parent = outer->parent;
+            s->lhs->hoisted = true;      // frame-constant operands under frame-constant control now: what the next call's arguments may rest on
+        }
         home->insert(at, order.begin(), order.end());
         moved_any = true;
     }
     return moved_any;
 }
 
+// analyze_frame_constants_once until the marks stand still: what a loop of both slices leaves behind (loop_const) is a
+// frame constant to the code behind it, which the next run then sees
+static void analyze_to_fixpoint(FilterCode &code) {
+    for (Value &v : code.values) v.loop_const = false;
+    size_t before = ~(size_t)0;
+    for (int iter = 0; iter < 6; ++iter) {
+        analyze_frame_constants_once(code);
+        size_t now = 0;
+        for (const Value &v : code.values) now += (v.hoisted ? 1 : 0) + (v.loop_const ? 0x10000 : 0);
+        if (now == before) break;
+        before = now;
+    }
+}
+
 void analyze_frame_constants(FilterCode &code) {
-    analyze_frame_constants_once(code);
-    if (hoist_speculative(code)) analyze_frame_constants_once(code);
-    if (hoist_native_calls(code)) analyze_frame_constants_once(code);
+    analyze_to_fixpoint(code);
+    if (hoist_speculative(code)) analyze_to_fixpoint(code);
+    if (hoist_native_calls(code)) analyze_to_fixpoint(code);
 }
 
 static void analyze_frame_constants_once(FilterCode &code) {
     for (Value &v : code.values) v.hoisted = true;
     bool changed = true;
-    auto prim_hoisted = [](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted; };
+    // Images that are (or may be, through copies, phis and resize wrappers) results of native filters / render(): their
+    // pixels exist only after the host has run the filter's kernels, *behind* the frame-constant code -- a fetch from one
+    // is per-pixel code even at frame-constant coordinates (the reference's init_frame computes the map on the spot).
+    std::set<const Value *> native_img;
+    {
+        bool grew = true;
+        std::function<void(Block &)> scan = [&](Block &b) {
+            for (Stmt *s : b) {
+                if (s->kind == Stmt::Assign || s->kind == Stmt::Phi) {
+                    bool d = is_native_call(s);
+                    if (!d && s->lhs->var && s->lhs->var->type == Ty::Image) {
+                        auto from = [&](const Rhs &r) {
+                            if (r.kind == Rhs::Prim && r.prim.kind == Primary::Val && native_img.count(r.prim.value)) return true;
+                            for (const Primary &p : r.args)
+                                if (p.kind == Primary::Val && native_img.count(p.value)) return true;
+                            return false;
+                        };
+                        d = from(s->rhs) || (s->kind == Stmt::Phi && from(s->rhs2));
+                    }
+                    if (d && native_img.insert(s->lhs).second) grew = true;
+                }
+                if (s->kind == Stmt::If) { scan(s->then_); scan(s->else_); scan(s->phis); }
+                if (s->kind == Stmt::While) { scan(s->phis); scan(s->body); }
+            }
+        };
+        while (grew) { grew = false; scan(code.body); }
+    }
+    // (loop_const, from the previous run: the value a loop of both slices leaves behind is a frame constant to the code
+    // behind the loop -- the prologue ran its copy of the loop; inside the loop everything is demoted below anyway)
+    auto prim_hoisted = [](const Primary &p) { return p.kind != Primary::Val || p.value->index < 0 || p.value->hoisted || p.value->loop_const; };
     auto rhs_hoisted = [&](const Rhs &r) {
         if (r.kind == Rhs::Internal) return internal_is_frame_const(r.internal);
         if (r.kind == Rhs::Op && !r.op->pure) return false;
+        if (r.kind == Rhs::Op && !strcmp(r.op->cname, "ORIG_VAL") && r.args.size() >= 3 && r.args[2].kind == Primary::Val &&
+            native_img.count(r.args[2].value))
+            return false;
         if (r.kind == Rhs::Prim) return prim_hoisted(r.prim);
         for (const Primary &p : r.args)
             if (!prim_hoisted(p)) return false;
@@ -614,6 +749,7 @@ static void analyze_frame_constants_once(FilterCode &code) {
         for (Value &v : code.values) after += v.hoisted;
         if (before == after) { mark(code.body, h, p); break; }
     }
+    mark_dual_loops(code);
 }
 
 }  // namespace mm

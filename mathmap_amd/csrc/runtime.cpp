@@ -871,6 +871,8 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
             rec.args[i].img.idx = (int)images_k.size();
             rec.args[i].img.pw = d.w;
             rec.args[i].img.ph = d.h;
+            rec.args[i].img.xf = rec.args[i].img.yf = 1.0f;      // a plain map: the closure's render kernel has applied the
+            rec.args[i].img.resized = 0;                          // wrapper's factors to its coordinates already (lower.cpp)
             images_k.push_back(d);
             has_closure_arg = true;
         }
@@ -1095,6 +1097,7 @@ int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int re
     a.edge_color_y = inv->edge_color_y;
     a.uservals = inv->d_uv;
     a.images = inv->d_images;
+    a.num_images = (uint32_t)inv->images.size();
     a.curves = inv->d_curves;
     a.gradients = inv->d_gradients;
     a.out = out_device;

@@ -498,20 +498,23 @@ mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h) {
     mmo_image_desc *dst;
     mmo_image out;
     const mmo_image_desc *src = &A->images[in.idx];
-    if (src->kind != MMO_IMG_FLOATMAP) slot = mmo_memo_slot(A, slot, 2, in.idx, 0, 0.0f, 0.0f);
-    m = &A->memo[slot];
-    dst = &A->images[A->native_slot_base + slot];
-    if (src->kind == MMO_IMG_FLOATMAP) {
-        /* a closure the harness rendered beforehand: render_image made a new, plain float map of it
-         * (no resize wrapper on the result, builtins.c:270-271,345) */
-        if (A->closure_base >= 0 && in.idx >= A->closure_base) {
-            in.pw = src->w;
-            in.ph = src->h;
-            in.xf = in.yf = 1.0f;
-            in.resized = 0;
-        }
+    /* a closure the harness rendered beforehand: render_image made a new, plain float map of it
+     * (no resize wrapper on the result, builtins.c:270-271,345) */
+    if (src->kind == MMO_IMG_FLOATMAP && A->closure_base >= 0 && in.idx >= A->closure_base) {
+        in.pw = src->w;
+        in.ph = src->h;
+        in.xf = in.yf = 1.0f;
+        in.resized = 0;
         return in;
     }
+    /* builtins.c:273-274: a *plain* float map is returned as it is.  One behind a resize wrapper (what filter code hands to
+     * render(): every image value is RESIZE_IMAGE(STRIP_RESIZE(..)), drawable.c:213-227) is of type IMAGE_RESIZE and takes
+     * the sampling branch like a drawable does: a new map, each pixel ORIG_VAL at the new map's own unit coordinates --
+     * scaled by the wrapper's factors, nearest texel, zeros outside (builtins.c:303-343, 247-265) */
+    if (src->kind == MMO_IMG_FLOATMAP && !in.resized) return in;
+    slot = mmo_memo_slot(A, slot, 2, in.idx, 0, in.resized ? in.xf : 1.0f, in.resized ? in.yf : 1.0f);
+    m = &A->memo[slot];
+    dst = &A->images[A->native_slot_base + slot];
     if (!(m->valid && m->func == 2 && m->in_idx == in.idx && m->w == w && m->h == h)) {
         if (m->map == NULL || m->w != w || m->h != h) {
             free(m->map);
@@ -523,7 +526,8 @@ mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h) {
         m->func = 2;
         m->in_idx = in.idx;
         m->in2_idx = 0;
-        m->a1 = m->a2 = 0.0f;
+        m->a1 = in.resized ? in.xf : 1.0f;
+        m->a2 = in.resized ? in.yf : 1.0f;
         m->w = w;
         m->h = h;
     }

@@ -798,3 +798,45 @@ def test_oracle_native_results_are_cached_per_argument_set():
     b = CpuFilter(mm.Filter(flat).ir_json_raw).render(w, h, images={"in": img})
     assert np.array_equal(a, b)
     assert not np.array_equal(a, CpuFilter(mm.Filter("filter i (image in) in(xy) end").ir_json_raw).render(w, h, images={"in": img}))
+
+
+def test_oracle_render_samples_a_float_map_behind_its_resize_wrapper():
+    """render_image returns a *plain* float map as it is (builtins.c:273-274); the image filter code hands to render()
+    is behind a resize wrapper (IMAGE_RESIZE) and is sampled into a new map (builtins.c:303-343): a copy on a square
+    frame; on 96 x 64 every new row r holds source row lrintf(1.5 (r - 31.5) + 31.5) -- or zeros where that is outside."""
+    import mathmap_amd as mm
+    from oracle.ccgen import CpuFilter
+    blur = "filter f (image in) b = gaussian_blur(in, 0.06, 0.03); b(xy) end"
+    both = "filter f (image in) b = gaussian_blur(in, 0.06, 0.03); rr = render(b); rr(xy) end"
+    for w, h in ((64, 64), (96, 64)):
+        img = F.synthetic_image(w, h, seed=15)
+        a = CpuFilter(mm.Filter(blur).ir_json_raw).render(w, h, images={"in": img}, floatmap=True)
+        b = CpuFilter(mm.Filter(both).ir_json_raw).render(w, h, images={"in": img}, floatmap=True)
+        if w == h:
+            assert np.array_equal(a, b)
+            continue
+        # the frame's rows sample the new map's rows 11..52 (its unit coordinates +-0.663); those hold the blur's rows
+        # lrintf(1.5 (R - 31.5) + 31.5); the blur itself is sampled at rows lrintf(0.663 (r - 31.5) + 31.5) * 1.5 ...: compare
+        # through the row maps
+        f32 = np.float32
+        def row_of_unit(y, n):          # get_floatmap_pixel: lrintf(ay y + by), ay = -(n - 1) / 2
+            by = f32(f32(n - 1) / 2.0)
+            ay = f32(by * f32(-1.0))
+            return int(np.rint(f32(f32(ay * y) + by)))
+        rows_differ = 0
+        for r in range(h):
+            y = f32(f32((-(r) + (h - 1) / 2.0) / ((h - 1) / 2.0)) * f32(h / w))      # CALC_VIRTUAL_Y times H / max(W, H)
+            new_row = row_of_unit(y, h)                                              # rr is a plain map: no factor
+            fy = f32(f32(f32(new_row) - f32((h - 1) / 2.0)) / f32(-(h - 1) / 2.0))   # render_image's own coordinate of that row
+            src_row = row_of_unit(f32(fy * f32(1.5)), h)
+            direct_row = row_of_unit(f32(y * f32(1.5)), h)                           # b(xy): through the wrapper
+            if 0 <= src_row < h:
+                # rr's row `new_row' is the blur's row `src_row'; the frame's row r of `blur' is the blur's row `direct_row'
+                if src_row == direct_row:
+                    assert np.array_equal(b[r], a[r]), r
+                else:
+                    rows_differ += 1
+            else:
+                assert not b[r].any(), r
+                rows_differ += 1
+        assert rows_differ > 0

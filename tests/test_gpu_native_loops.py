@@ -169,3 +169,89 @@ def test_results_of_earlier_iterations_stay_readable():
     assert np.array_equal(got, want), stats(got, want)
     _, ui = make_invocation(KEEP_UNROLLED, w, h, {}, {"in": img})
     assert np.array_equal(got, ui.render(t=0.25))
+
+
+# ---- loops that hold native calls *and* per-pixel code: emitted in both slices (passes.cpp mark_dual_loops) ----
+# the loop-constant part (the image chain, its counters and conditions) runs in the prologue, where the calls are
+# numbered; the pixel slice runs the whole loop and takes the n-th call's result for its n-th call
+GLOW = """
+filter glow (image in, float s: 0-1 (0.015), int n: 0-4 (3), int mode: 0-1 (1))
+  img = in; acc = in(xy) * 0.4; i = 0;
+  while i < n do
+    img = gaussian_blur(img, s * (i + 1), s * (i + 1));
+    acc = acc + img(xy) * 0.2;
+    if x > -0.2 then q = gaussian_blur(img, s, s * 3); acc = acc + q(xy * 0.9) * 0.1 else acc = acc * 0.9 end;
+    if mode > 0 then img = render(img); 0 else 0 end;
+    i = i + 1
+  end;
+  last = gaussian_blur(img, s, s);
+  acc + last(xy) * 0.2
+end
+"""
+
+GLOW_UNROLLED_2 = """
+filter glow2 (image in, float s: 0-1 (0.015))
+  acc = in(xy) * 0.4;
+  a1 = gaussian_blur(in, s, s); acc = acc + a1(xy) * 0.2;
+  q1 = gaussian_blur(a1, s, s * 3);
+  if x > -0.2 then acc = acc + q1(xy * 0.9) * 0.1 else acc = acc * 0.9 end;
+  r1 = render(a1);
+  a2 = gaussian_blur(r1, s * 2, s * 2); acc = acc + a2(xy) * 0.2;
+  q2 = gaussian_blur(a2, s, s * 3);
+  if x > -0.2 then acc = acc + q2(xy * 0.9) * 0.1 else acc = acc * 0.9 end;
+  r2 = render(a2);
+  last = gaussian_blur(r2, s, s);
+  acc + last(xy) * 0.2
+end
+"""
+
+
+@pytest.mark.parametrize("n,mode", [(0, 1), (1, 0), (2, 1), (4, 1), (3, 0)])
+def test_loop_with_native_calls_and_per_pixel_code(n, mode):
+    w, h = 160, 96
+    img = F.synthetic_image(w, h, seed=13)
+    flt, inv = make_invocation(GLOW, w, h, {"n": n, "mode": mode}, {"in": img})
+    got = inv.render(t=0.25)
+    want = CpuFilter(flt.ir_json_raw).render(w, h, uservals={"n": n, "mode": mode}, images={"in": img}, t=0.25)
+    assert np.array_equal(got, want), stats(got, want)
+    if (n, mode) == (2, 1):
+        _, ui = make_invocation(GLOW_UNROLLED_2, w, h, {}, {"in": img})
+        assert np.array_equal(got, ui.render(t=0.25))
+
+
+def test_frame_constant_fetch_from_a_native_result_waits_for_the_result():
+    """`b(xy:[0.1, 0.2])` has frame-constant coordinates, but b's pixels exist only after the host has run the blur,
+    behind the prologue: the fetch is per-pixel code (it was hoisted into the prologue until round 3 and read the map of
+    the previous frame -- or none)."""
+    w, h = 128, 80
+    img = F.synthetic_image(w, h, seed=14)
+    src = ("filter f (image in, float s: 0-1 (0.02)) b = gaussian_blur(in, s * (1 + t), s); c = b(xy:[0.1, 0.2]); "
+           "d = if c[0] > 0.3 then b(xy) else in(xy) end; d * 0.5 + c * 0.5 end")
+    flt, inv = make_invocation(src, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for t in (0.0, 0.5, 0.25):
+        got = inv.render(t=t)
+        want = cf.render(w, h, images={"in": img}, t=t)
+        assert np.array_equal(got, want), (t, stats(got, want))
+
+
+@pytest.mark.parametrize("size", [(96, 64), (64, 96), (80, 80)])
+def test_render_of_a_native_result_on_a_non_square_frame(size):
+    """What filter code hands to render() is the image behind its resize wrapper (every image value is
+    RESIZE_IMAGE(STRIP_RESIZE(..)), drawable.c:213-227): of type IMAGE_RESIZE, so render_image's `a float map is its own
+    rendering' shortcut (builtins.c:273-274) does not apply and the map is *sampled* into a new one -- each new pixel
+    at its own unit coordinates times the wrapper's factors, nearest texel, zeros outside (builtins.c:303-343).  On a
+    square frame that is a copy; on a non-square one it resamples (every third row twice, one black row at 96 x 64).
+    Until round 3 both the oracle and the HIP path took the shortcut (differently): found by tools/fuzz_native_flow.py."""
+    w, h = size
+    img = F.synthetic_image(w, h, seed=15)
+    src = ("filter f (image in, float s: 0-1 (0.02)) b = gaussian_blur(in, s * 3, s * 1.5); rr = render(b); "
+           "c = gaussian_blur(rr, s, s); rr(xy) * 0.5 + c(xy * 0.9) * 0.3 + render(rr)(xy) * 0.2 end")
+    src = src.replace("render(rr)(xy)", "r2(xy)").replace("c = gaussian_blur", "r2 = render(rr); c = gaussian_blur")
+    flt, inv = make_invocation(src, w, h, {}, {"in": img})
+    got = inv.render(t=0.25)
+    want = CpuFilter(flt.ir_json_raw).render(w, h, images={"in": img}, t=0.25)
+    assert np.array_equal(got, want), stats(got, want)
+    plain = "filter f (image in, float s: 0-1 (0.02)) b = gaussian_blur(in, s * 3, s * 1.5); c = gaussian_blur(b, s, s); b(xy) * 0.7 + c(xy * 0.9) * 0.3 end"
+    _, pi = make_invocation(plain, w, h, {}, {"in": img})
+    assert np.array_equal(got, pi.render(t=0.25)) == (w == h)      # a copy on the square frame only
