@@ -19,18 +19,35 @@ from oracle.ccgen import CpuFilter  # noqa: E402
 
 
 class Gen:
-    def __init__(self, seed):
+    def __init__(self, seed, rich=False):
         self.r = random.Random(seed)
+        self.rich = rich             # closures handed to natives, the FFT filters
+        self.in_pixel_now = False
         self.calls_in_loops = 0      # static bound on calls made from in-loop sites (16 dynamic entries per frame)
         self.tmp = 0
 
     def dev(self):
-        return "s * %g" % self.r.choice([0.5, 1, 1.5, 2, 3])
+        # (rich: no sigma below 0.5 px -- the FIR path picks do_full_lre or do_encoded_lre per line by counting *equal*
+        # neighbours (gauss.c:333-375), so behind an FFT filter, whose last bits differ between FFT implementations, it
+        # switches paths on rounding noise: seed 36 of the first rich run, 32 levels apart.  The reference would differ
+        # from itself with another FFTW build.)
+        return "s * %g" % self.r.choice([1, 1.5, 2, 3] if self.rich else [0.5, 1, 1.5, 2, 3])
 
     def call(self, img):
-        if self.r.random() < 0.2:
+        k = self.r.random()
+        if k < 0.2:
             return "render(%s)" % img
+        if self.rich and k < 0.3 and not self.in_loop and not self.in_pixel_now:      # a closure image (refused inside loops)
+            return self.closure_call(img)
+        if self.rich and k < 0.38:
+            return self.r.choice(["convolve(%s, in, 1, 0)", "half_convolve(%s, in, 0)", "visualize_fft(%s, 0)"]) % img
         return "gaussian_blur(%s, %s, %s)" % (img, self.dev(), self.dev())
+
+    def closure_call(self, img):
+        c = "inner(%s, %g)" % (img, self.r.choice([0.7, 1, 1.2]))
+        if self.r.random() < 0.3:
+            return "render(%s)" % c
+        return "gaussian_blur(%s, %s, %s)" % (c, self.dev(), self.dev())
 
     def fresh(self):
         self.tmp += 1
@@ -42,6 +59,7 @@ class Gen:
         for _ in range(self.r.randint(1, 3)):
             k = self.r.random()
             if k < 0.35 or depth >= 3:
+                self.in_pixel_now = in_pixel
                 if in_pixel:
                     q = self.fresh()
                     out.append("%s = %s; acc = acc + %s(xy * %g) * %g" % (q, self.call("img"), q, self.r.choice([1, 0.9, 1.1]),
@@ -75,18 +93,21 @@ class Gen:
     def filter(self):
         self.in_loop = False
         body = self.block(0, 1, False)
-        return ("filter f (image in, float s: 0-1 (0.02), int mode: 0-2 (1), int n: 0-3 (2))\n  img = in; acc = rgba:[0, 0, 0, 0];\n  "
+        inner = "filter inner (image in, float k: 0-2 (1.0))\n  in(xy * k) * 0.8 + rgba:[t * 0.3, 0, 0.1, 0]\nend\n\n" if self.rich else ""
+        return (inner + "filter f (image in, float s: 0-1 (0.02), int mode: 0-2 (1), int n: 0-3 (2))\n  img = in; acc = rgba:[0, 0, 0, 0];\n  "
                 + ";\n  ".join(body) + ";\n  acc + img(xy) * 0.4\nend\n")
 
 
 def main():
     from mathmap_amd._lib import selftest_lib
     lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
-    w, h = 96, 64
-    img = np.ascontiguousarray(F.synthetic_image(w, h, seed=3))
-    bad, ran, skipped, calls = [], 0, 0, 0
+    rich = len(sys.argv) > 3 and sys.argv[3] == "rich"
+    bad, ran, skipped, calls, refused = [], 0, 0, 0, 0
     for seed in range(lo, hi):
-        g = Gen(seed)
+        w, h = [(96, 64), (64, 96), (80, 80), (112, 48)][seed % 4] if rich else (96, 64)
+        iw, ih = [(w, h), (50, 70), (w, h), (131, 40)][(seed // 4) % 4] if rich else (w, h)      # the input's own size
+        img = np.ascontiguousarray(F.synthetic_image(iw, ih, seed=3))
+        g = Gen(seed, rich)
         src = g.filter()
         if g.calls_in_loops > 16 or "gaussian_blur" not in src and "render" not in src:
             skipped += 1
@@ -104,7 +125,9 @@ def main():
                 want = cf.render(w, h, uservals={"mode": mode, "n": n}, images={"in": img}, t=t)
                 if not np.array_equal(got, want):
                     d = np.abs(got.astype(int) - want.astype(int))
-                    bad.append((seed, mode, n, t, int(d.max()), int((d > 0).sum())))
+                    fft = "convolve(" in src or "visualize_fft(" in src      # hipFFT against the oracle's own DFT: 1 LSB
+                    if not (fft and d.max() <= 1 and (d > 0).sum() <= 0.001 * d.size):
+                        bad.append((seed, mode, n, t, int(d.max()), int((d > 0).sum())))
             ran += 1
             calls += flt.num_native_calls
             if seed % 4 == 0:      # the reference-ABI tier on the same text (defaults of the user values)
@@ -112,17 +135,22 @@ def main():
                 want.set_image("in", img)
                 ref = want.render(t=0.25)
                 out = np.zeros((h, w, 4), np.uint8)
-                rc = selftest_lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p), w, h, 3, w, h, 0.25, 2,
+                rc = selftest_lib().mmhip_selftest_abi_roundtrip(src.encode(), 1, img.ctypes.data_as(C.c_void_p), iw, ih, 3, w, h, 0.25, 2,
                                                                  out.ctypes.data_as(C.c_void_p))
                 if rc != 0:
                     bad.append((seed, "abi", selftest_lib().mmhip_selftest_error().decode()[:200]))
                 elif not np.array_equal(out, ref):
                     bad.append((seed, "abi differs"))
         except Exception as e:
-            bad.append((seed, "error", str(e).splitlines()[0][:200]))
+            msg = str(e).splitlines()[0][:200]
+            if rich and ("inside a loop is not supported" in msg or "pixel-dependent arguments" in msg or "needs frame-constant arguments" in msg or
+                         "hands another closure to a native filter" in msg):
+                refused += 1      # documented refusals (closures in loops / under pixel-dependent control): loud, not wrong
+            else:
+                bad.append((seed, "error", msg))
         if seed % 25 == 0:
             print("  ran", ran, "skipped", skipped, "bad so far", len(bad), flush=True)
-    print("filters:", ran, "skipped:", skipped, "native call sites:", calls, "bad:", bad)
+    print("filters:", ran, "skipped:", skipped, "refused:", refused, "native call sites:", calls, "bad:", bad)
     return 1 if bad else 0
 
 
