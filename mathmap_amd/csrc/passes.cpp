@@ -101,6 +101,47 @@ bool copy_propagate(FilterCode &code) {
     return changed;
 }
 
+// Liveness from the roots -- the results, the conditions of the control statements, impure statements -- instead of use
+// counts: removes values that only feed each other around a loop (`while .. do img = render(img) end` with img unused behind
+// it), which eliminate_dead_code's counts keep.  For the render code of a closure image: it is the main filter's code once
+// more with another result, most of it dead, and what stays of the main code's native calls is *run* again (runtime.cpp
+// render_closure) -- a consumer of the closure itself among them would be a closure inside a closure's render.
+bool eliminate_dead_cycles(FilterCode &code) {
+    std::set<const Value *> live;
+    std::vector<const Value *> work;
+    auto mark = [&](const Primary &p) { if (p.kind == Primary::Val && p.value->index >= 0 && live.insert(p.value).second) work.push_back(p.value); };
+    auto mark_rhs = [&](const Rhs &r) { if (r.kind == Rhs::Prim) mark(r.prim); for (const Primary &p : r.args) mark(p); };
+    for_each_stmt(code.body, [&](Stmt *s) {
+        if (s->kind == Stmt::If || s->kind == Stmt::While) mark_rhs(s->cond);
+        if (s->kind == Stmt::Assign && !rhs_pure(s->rhs)) { mark(Primary::V(s->lhs)); }
+    });
+    for (int i = 0; i < 4; ++i)
+        if (code.result[i]) mark(Primary::V(code.result[i]));
+    while (!work.empty()) {
+        const Value *v = work.back();
+        work.pop_back();
+        const Stmt *d = v->def;
+        if (!d) continue;
+        mark_rhs(d->rhs);
+        if (d->kind == Stmt::Phi) mark_rhs(d->rhs2);
+    }
+    bool changed = false;
+    std::function<void(Block &)> sweep = [&](Block &b) {
+        Block out;
+        for (Stmt *s : b) {
+            bool dead = (s->kind == Stmt::Assign || s->kind == Stmt::Phi) && !live.count(s->lhs) && (s->kind == Stmt::Phi || rhs_pure(s->rhs));
+            if (s->kind == Stmt::If) { sweep(s->then_); sweep(s->else_); sweep(s->phis); }
+            if (s->kind == Stmt::While) { sweep(s->phis); sweep(s->body); }
+            if (dead) changed = true;
+            else out.push_back(s);
+        }
+        b.swap(out);
+    };
+    sweep(code.body);
+    if (changed) eliminate_dead_code(code);      // (conditionals emptied by the sweep)
+    return changed;
+}
+
 bool eliminate_dead_code(FilterCode &code) {
     bool any = false;
     for (;;) {

@@ -7,6 +7,7 @@
 namespace mm {
 bool copy_propagate(FilterCode &code);
 bool eliminate_dead_code(FilterCode &code);
+bool eliminate_dead_cycles(FilterCode &code);   // what only feeds itself around a loop (closure render code: passes.cpp)
 bool loop_carried_cse(FilterCode &code);
 bool common_subexpressions(FilterCode &code);
 void optimize(FilterCode &code);

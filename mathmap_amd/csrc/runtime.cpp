@@ -92,6 +92,7 @@ static mmhip_filter *compile_source(const char *source, const mmhip_options *opt
         for (auto &sub : f->code->closure_renders) {
             if (consts) specialize_constants(*sub);
             optimize(*sub);
+            eliminate_dead_cycles(*sub);
             analyze_frame_constants(*sub);
         }
         for (auto &fn : f->code->functions) optimize(*fn);     // function bodies: no frame-constant slice, no user-value literals
@@ -160,6 +161,7 @@ bool mmhip_filter_finalize(mmhip_filter *f, const KernelOptions &ko, std::string
         for (auto &sub : f->code->closure_renders) {
             sub->filter = f->module.main;
             optimize(*sub);
+            eliminate_dead_cycles(*sub);
             analyze_frame_constants(*sub);
         }
         for (auto &fn : f->code->functions) optimize(*fn);
@@ -690,7 +692,37 @@ static int recorded_calls(const KernelSource &ks, const std::vector<char> &host,
     return 0;
 }
 
-static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const HArgs &main_args, hipStream_t s) {
+// Is the call `c' recorded by a closure's render kernel the call `m' the main code has already made this frame?  The render
+// kernel evaluates the main filter's code once more (it computes the closure's arguments), native calls included: those are
+// the same calls on the same images -- in the reference the closure's argument simply *is* the image the main code computed,
+// and its cache would answer (native-filters/cache.c:110-147).  Scalars by their bits, images by what they refer to: an input
+// image or closure by its handle, a native result by the main call its own producer was matched with (`alias': render
+// kernel's entry -> main's image-table slot, -1 unmatched).
+static bool same_native_call(const RecordedCall &c, const RecordedCall &m, const std::vector<int> &alias, int closure_slot_base) {
+    if (*c.func != *m.func || c.rec.nargs != m.rec.nargs) return false;
+    for (int i = 0; i < c.rec.nargs && i < 4; ++i) {
+        const HNativeArg &x = c.rec.args[i], &y = m.rec.args[i];
+        if (x.kind != y.kind) return false;
+        if (x.kind != 2) {
+            if (x.i != y.i || memcmp(&x.f, &y.f, sizeof x.f) != 0) return false;
+            continue;
+        }
+        int idx = x.img.idx;
+        const int rel = idx - closure_slot_base;
+        if (rel >= 0 && rel < (int)alias.size()) {
+            if (alias[rel] < 0) return false;
+            idx = alias[rel];
+        }
+        if (idx != y.img.idx || x.img.pw != y.img.pw || x.img.ph != y.img.ph || x.img.resized != y.img.resized ||
+            memcmp(&x.img.xf, &y.img.xf, sizeof x.img.xf) != 0 || memcmp(&x.img.yf, &y.img.yf, sizeof x.img.yf) != 0)
+            return false;
+    }
+    return true;
+}
+
+// `main_done': the main code's calls run so far this frame (their maps are valid)
+static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const HArgs &main_args, hipStream_t s,
+                          const std::vector<RecordedCall> &main_done) {
     mmhip_closure_kernel &ck = f->closures[cid];
     auto &st = inv->closure_state[cid];
     const int w = main_args.render_width, h = main_args.render_height;
@@ -752,9 +784,25 @@ static int render_closure(mmhip_invocation *inv, mmhip_filter *f, int cid, const
         HIP_TRY(hipStreamSynchronize(s));
         std::vector<RecordedCall> calls;
         if (recorded_calls(ck.ks, host, &calls) != 0) return -1;
+        std::vector<int> alias(ck.ks.natives.size(), -1);
         for (const RecordedCall &call : calls) {
             const size_t k = call.k;
             const HNativeRec &rec = call.rec;
+            // a call of the main code's copy: the main code has its result already (same_native_call)
+            bool aliased = false;
+            static const bool no_alias = getenv("MMHIP_NO_NATIVE_ALIAS") != nullptr;      // (experiments: run every recorded call)
+            for (const RecordedCall &m : main_done) {
+                if (no_alias) break;
+                const int mslot = inv->native_slot_base + (int)m.k;
+                if (!same_native_call(call, m, alias, st.native_slot_base) || !inv->native_maps[m.k] || inv->images[mslot].kind != IMG_FLOATMAP ||
+                    inv->images[mslot].w != w || inv->images[mslot].h != h || inv->native_rows[m.k].first > 0 || inv->native_rows[m.k].second < h)
+                    continue;
+                inv->images[st.native_slot_base + (int)k] = inv->images[mslot];      // the same map under the render kernel's handle
+                alias[k] = mslot;
+                aliased = true;
+                break;
+            }
+            if (aliased) continue;
             for (int i = 0; i < rec.nargs && i < 4; ++i)
                 if (rec.args[i].kind == 2 && rec.args[i].img.idx <= -2)
                     return fail("a filter closure rendered for a native filter hands another closure to a native filter: not supported");
@@ -819,7 +867,7 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         }
     }
     bool table_changed = false;
-    std::vector<RecordedCall> calls;
+    std::vector<RecordedCall> calls, done;      // done: calls whose maps stand (what a closure's render kernel may refer to)
     if (recorded_calls(f->ks, host, &calls) != 0) return -1;
     for (const RecordedCall &call : calls) {
         const size_t k = call.k;
@@ -857,7 +905,7 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
             if (rec.args[i].kind != 2 || rec.args[i].img.idx > -2) continue;
             const int cid = -2 - rec.args[i].img.idx;
             if (cid >= (int)f->closures.size()) return fail("internal: closure image without a render kernel");
-            if (render_closure(inv, f, cid, a, s) != 0) return -1;
+            if (render_closure(inv, f, cid, a, s, done) != 0) return -1;
             if (images_k.empty()) images_k = inv->images;
             HImageDesc d{};
             d.data = inv->closure_state[cid].map;
@@ -884,8 +932,10 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
                 deps.push_back(inv->native_gen[rec.args[i].img.idx - inv->native_slot_base]);
         if (!has_closure_arg && inv->native_maps[k] && inv->native_memo_gen[k] == inv->input_generation &&
             memcmp(&inv->native_memo[k], &rec, sizeof rec) == 0 && inv->native_memo_deps[k] == deps &&
-            inv->native_rows[k].first <= want_lo && inv->native_rows[k].second >= want_hi)
+            inv->native_rows[k].first <= want_lo && inv->native_rows[k].second >= want_hi) {
+            done.push_back(call);
             continue;
+        }
         size_t bytes = (size_t)a.render_width * a.render_height * 16;
         if (!inv->native_maps[k]) {
             HIP_TRY(hipMalloc(&inv->native_maps[k], bytes));
@@ -935,6 +985,7 @@ static int run_natives(mmhip_invocation *inv, mmhip_filter *f, const HArgs &a, h
         inv->native_memo_gen[k] = inv->input_generation;
         inv->native_rows[k] = {got_lo, got_hi};
         table_changed = true;
+        done.push_back(call);
     }
     // dynamic entries this frame did not use (the loop ran fewer times than before): their maps go back (a map is
     // 16 B per pixel of the frame; sixteen of them at 16384^2 are 69 GB)

@@ -520,8 +520,13 @@ class CpuFilter:
                     pass
         # closure images handed to native filters: each is rendered by its own code (render_image's closure
         # branch launches the closure's calc_lines), the IR dump carries that code under "closure_renders"
-        self.subs = [CpuFilter(dict(sub, functions=self.ir.get("functions", [])), extra_cflags)
-                     for sub in self.ir.get("closure_renders", [])]
+        # The render code of closure k evaluates the main filter's code once more (it computes the closure's arguments), and
+        # that code may hold native calls on the closures before it (`b = gaussian_blur(inner(in, ..)); c = gaussian_blur(inner(b, ..))`):
+        # closure k's own renders are the main filter's renders 0 .. k-1 (same numbering; an argument can only rest on what came before)
+        renders = self.ir.get("closure_renders", [])
+        self.subs = [CpuFilter(dict(sub, functions=self.ir.get("functions", []), closure_renders=sub.get("closure_renders") or renders[:k]),
+                               extra_cflags)
+                     for k, sub in enumerate(renders)]
         self.lib = C.CDLL(so)
         self.lib.mmo_xy_size.restype = C.c_int
         self.lib.mmo_init_frame.argtypes = [C.POINTER(_Args), C.c_void_p]

@@ -183,6 +183,7 @@ mmo_image mmo_native_half_convolve(const mmo_args *A, int slot, mmo_image in, mm
 mmo_image mmo_native_visualize_fft(const mmo_args *A, int slot, mmo_image in, float ignore_alpha);
 mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h);
 int mmo_memo_slot(const mmo_args *A, int site, int func, int in, int in2, float a1, float a2);
+const mmo_image_desc *mmo_desc_of(const mmo_args *A, int idx);   /* &A->images[idx], or an unbound image's descriptor for a handle outside the table */
 void mmo_render_image(const mmo_args *A, const mmo_image_desc *src, mmo_image srcv, int w, int h, float *out);
 void mmo_gauss_iir(float *map, int width, int height, float hdev, float vdev);
 void mmo_gauss_rle(float *map, int width, int height, float hdev, float vdev);

@@ -137,7 +137,7 @@ static double copy_and_add(double *dest, const float *src, int n) {
 /* the argument image as a float map of the given size: used as is when it already is one,
  * otherwise render_image (convolve.c:88-95) */
 static const float *as_floatmap(const mmo_args *A, mmo_image img, int w, int h, float **owned) {
-    const mmo_image_desc *src = &A->images[img.idx];
+    const mmo_image_desc *src = mmo_desc_of(A, img.idx);
     *owned = NULL;
     if (src->kind == MMO_IMG_FLOATMAP && src->w == w && src->h == h) return (const float *)src->data;
     *owned = malloc((size_t)w * h * 4 * sizeof(float));
@@ -183,9 +183,9 @@ mmo_image mmo_native_convolve(const mmo_args *A, int slot, mmo_image in, mmo_ima
     mmo_native_memo *m = &A->memo[slot = mmo_memo_slot(A, slot, 3, in.idx, filter.idx, normalize_f, copy_alpha_f)];
     const int normalize = normalize_f != 0.0, copy_alpha = copy_alpha_f != 0.0;
     int w = A->render_width, h = A->render_height;
-    if (A->images[in.idx].kind == MMO_IMG_FLOATMAP) {
-        w = A->images[in.idx].w;
-        h = A->images[in.idx].h;
+    if (mmo_desc_of(A, in.idx)->kind == MMO_IMG_FLOATMAP) {
+        w = mmo_desc_of(A, in.idx)->w;
+        h = mmo_desc_of(A, in.idx)->h;
     }
     if (!memo_hit(m, 3, in.idx, filter.idx, normalize_f, copy_alpha_f, w, h)) {
         float *own_in, *own_filter;
@@ -231,9 +231,9 @@ mmo_image mmo_native_half_convolve(const mmo_args *A, int slot, mmo_image in, mm
     mmo_native_memo *m = &A->memo[slot = mmo_memo_slot(A, slot, 4, in.idx, filter.idx, copy_alpha_f, 0.0f)];
     const int copy_alpha = copy_alpha_f != 0.0;
     int w = A->render_width, h = A->render_height;
-    if (A->images[in.idx].kind == MMO_IMG_FLOATMAP) {
-        w = A->images[in.idx].w;
-        h = A->images[in.idx].h;
+    if (mmo_desc_of(A, in.idx)->kind == MMO_IMG_FLOATMAP) {
+        w = mmo_desc_of(A, in.idx)->w;
+        h = mmo_desc_of(A, in.idx)->h;
     }
     if (!memo_hit(m, 4, in.idx, filter.idx, copy_alpha_f, 0.0f, w, h)) {
         float *own_in, *own_filter;
@@ -273,9 +273,9 @@ mmo_image mmo_native_visualize_fft(const mmo_args *A, int slot, mmo_image in, fl
     mmo_native_memo *m = &A->memo[slot = mmo_memo_slot(A, slot, 5, in.idx, -1, ignore_alpha_f, 0.0f)];
     const int ignore_alpha = ignore_alpha_f != 0.0;
     int w = A->render_width, h = A->render_height;
-    if (A->images[in.idx].kind == MMO_IMG_FLOATMAP) {
-        w = A->images[in.idx].w;
-        h = A->images[in.idx].h;
+    if (mmo_desc_of(A, in.idx)->kind == MMO_IMG_FLOATMAP) {
+        w = mmo_desc_of(A, in.idx)->w;
+        h = mmo_desc_of(A, in.idx)->h;
     }
     if (!memo_hit(m, 5, in.idx, -1, ignore_alpha_f, 0.0f, w, h)) {
         float *own_in;

@@ -33,7 +33,9 @@ mmo_image mmo_closure_image(const mmo_args *A, int closure_id) {
     mmo_image im = {-1, 0, 0, 1.0f, 1.0f, 0};
     im.pw = A->img_width;
     im.ph = A->img_height;
-    if (closure_id >= 0 && A->closure_base >= 0) im.idx = A->closure_base + closure_id;
+    /* (a render's own code evaluates the main filter's code once more: closures from this one on are not rendered for it --
+     * their consumers are dead code there -- and read as no image) */
+    if (closure_id >= 0 && A->closure_base >= 0 && A->closure_base + closure_id < A->num_images) im.idx = A->closure_base + closure_id;
     return im;
 }
 
@@ -431,6 +433,16 @@ void mmo_gauss_rows_horizontal(float *vmid, int width, int height, int nrows, fl
     free(val_p); free(val_m); free(src); free(dest);
 }
 
+/* The descriptor behind an image handle.  A handle outside the table (the null image, idx -1: what a closure that was not
+ * rendered for this code reads as -- mmo_closure_image) is an unbound image, not whatever lies next to the table. */
+const mmo_image_desc *mmo_desc_of(const mmo_args *A, int idx) {
+    static mmo_image_desc nul;      /* (written with the same bytes by every caller) */
+    if (idx >= 0 && idx < A->num_images) return &A->images[idx];
+    memset(&nul, 0, sizeof nul);
+    nul.kind = MMO_IMG_NULL;
+    return &nul;
+}
+
 /* The reference caches native-filter results per invocation under (filter, arguments) (native-filters/cache.c:110-156): every
  * distinct argument set has an image of its own, whichever call site asked.  Here: entry `site` for the first argument set a
  * call site sees; a site that runs again with other arguments (inside a loop -- each pixel runs the loop anew) finds or takes
@@ -456,7 +468,7 @@ mmo_image mmo_native_gaussian_blur(const mmo_args *A, int slot, mmo_image in, fl
     mmo_image out;
     int w = A->render_width, h = A->render_height;
     if (!(m->valid && m->func == 1 && m->in_idx == in.idx && m->a1 == hdev && m->a2 == vdev && m->w == w && m->h == h)) {
-        const mmo_image_desc *src = &A->images[in.idx];
+        const mmo_image_desc *src = mmo_desc_of(A, in.idx);
         float horizontal_std_dev, vertical_std_dev;
         if (m->map == NULL || m->w != w || m->h != h) {
             free(m->map);
@@ -497,7 +509,7 @@ mmo_image mmo_render(const mmo_args *A, int slot, mmo_image in, int w, int h) {
     mmo_native_memo *m;
     mmo_image_desc *dst;
     mmo_image out;
-    const mmo_image_desc *src = &A->images[in.idx];
+    const mmo_image_desc *src = mmo_desc_of(A, in.idx);
     /* a closure the harness rendered beforehand: render_image made a new, plain float map of it
      * (no resize wrapper on the result, builtins.c:270-271,345) */
     if (src->kind == MMO_IMG_FLOATMAP && A->closure_base >= 0 && in.idx >= A->closure_base) {

@@ -235,3 +235,31 @@ def test_closure_render_survives_an_ir_round_trip():
     inv2.set("k", 1.1)
     inv2.set_image("in", img)
     assert np.array_equal(a, inv2.render(t=0.5))
+
+
+CHAINED = INNER + """
+filter outer (image in, float s: 0-1 (0.02))
+  b = gaussian_blur(inner(in, 0.7), s, s * 2);
+  c = gaussian_blur(inner(b, 1.2), s * 2, s);
+  d = render(inner(c, 0.9));
+  c(xy) * 0.5 + d(xy) * 0.3 + b(xy) * 0.2
+end
+"""
+
+
+@pytest.mark.parametrize("size", [(128, 128), (160, 96)])
+def test_closure_on_the_result_of_a_native_filter_on_a_closure(size):
+    """`c = gaussian_blur(inner(b, ..))` with `b = gaussian_blur(inner(in, ..))`: the second closure's render kernel evaluates
+    the main code once more to get at its argument `b`, and that code holds the first blur with *its* closure.  The
+    runtime recognises a call the main code has already made this frame (same filter, same arguments, images by what
+    they refer to) and hands the render kernel the main code's map -- in the reference `b` simply is that image, and
+    its cache would answer (native-filters/cache.c:110-147).  Until round 3: refused at run time, and a main-code
+    native call without a closure was run a second time."""
+    w, h = size
+    img = F.synthetic_image(w, h, seed=17)
+    flt, inv = make_invocation(CHAINED, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    for t in (0.25, 0.7):
+        got = inv.render(t=t)
+        want = cf.render(w, h, images={"in": img}, t=t)
+        assert np.array_equal(got, want), (t, stats(got, want))

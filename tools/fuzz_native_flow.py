@@ -99,6 +99,8 @@ class Gen:
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()      # a host-side crash names the call it happened in
     from mathmap_amd._lib import selftest_lib
     lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     rich = len(sys.argv) > 3 and sys.argv[3] == "rich"
@@ -113,6 +115,7 @@ def main():
             skipped += 1
             continue
         print("seed", seed, flush=True)      # (a GPU fault ends the process: the last line names the filter)
+        faulthandler.dump_traceback_later(120, exit=True)      # a hang: say where, and end
         try:
             flt = mm.Filter(src)
             cf = CpuFilter(flt.ir_json_raw)
@@ -143,8 +146,7 @@ def main():
                     bad.append((seed, "abi differs"))
         except Exception as e:
             msg = str(e).splitlines()[0][:200]
-            if rich and ("inside a loop is not supported" in msg or "pixel-dependent arguments" in msg or "needs frame-constant arguments" in msg or
-                         "hands another closure to a native filter" in msg):
+            if rich and ("inside a loop is not supported" in msg or "pixel-dependent arguments" in msg or "needs frame-constant arguments" in msg):
                 refused += 1      # documented refusals (closures in loops / under pixel-dependent control): loud, not wrong
             else:
                 bad.append((seed, "error", msg))
