@@ -840,3 +840,21 @@ def test_oracle_render_samples_a_float_map_behind_its_resize_wrapper():
                 assert not b[r].any(), r
                 rows_differ += 1
         assert rows_differ > 0
+
+
+def test_oracle_closure_on_the_result_of_a_native_filter_on_a_closure():
+    """`c = render(inner(b, 1.2))` with `b = gaussian_blur(inner(in, 0.7), ..)`: the render code of the second closure
+    evaluates the main filter's code once more, and that code holds the blur of the *first* closure -- whose render it
+    needs (closure k's renders are the main filter's renders 0 .. k-1).  Pinned against the flattened equivalent: on a
+    square frame render(closure)(xy) is the closure's body at the pixel, at t = 0."""
+    import mathmap_amd as mm
+    from oracle.ccgen import CpuFilter
+    inner = "filter inner (image in, float k: 0-2 (1.0))\n  in(xy * k) * 0.8 + rgba:[t * 0.3, 0, 0.1, 0]\nend\n\n"
+    head = "filter f (image in, float s: 0-1 (0.02))\n  b = gaussian_blur(inner(in, 0.7), s, s * 2);\n"
+    nested = inner + head + "  c = render(inner(b, 1.2));\n  c(xy)\nend\n"
+    flat = inner + head + "  b(xy * 1.2) * 0.8 + rgba:[0, 0, 0.1, 0]\nend\n"
+    w = h = 96
+    img = F.synthetic_image(w, h, seed=17)
+    a = CpuFilter(mm.Filter(nested).ir_json_raw).render(w, h, images={"in": img}, t=0.25)
+    b = CpuFilter(mm.Filter(flat).ir_json_raw).render(w, h, images={"in": img}, t=0.25)
+    assert np.array_equal(a, b)
