@@ -190,7 +190,8 @@ struct Generator {
                     return native_result_in_loop();      // a loop in both slices (passes.cpp mark_dual_loops): the prologue made this call
                 if (it == native_index.end() || sl != PROLOGUE)
                     throw CompileError("native filter `" + r.filter->name +
-                                       "' is called with pixel-dependent arguments; the HIP backend needs them frame-constant");
+                                       "' is called with pixel-dependent arguments (or, with a filter closure among them, under pixel-dependent "
+                                       "control); the HIP backend needs them frame-constant");
                 int k = it->second;
                 std::string s = native_call_head(k) + std::to_string(r.args.size());
                 for (size_t i = 0; i < r.args.size(); ++i) s += ", mm_narg(" + prim(r.args[i], sl) + ")";
