@@ -120,8 +120,11 @@ int mmhip_set_sampling_offset(mmhip_invocation *inv, float offset_x, float offse
 /* Renders rows [first_row, last_row) of region (region_x, region_y, region_w, region_h)
    at animation parameter t / frame into device memory `out_device` (row 0 of the
    band at out_device; bpp bytes per pixel, row_stride bytes per row; floatmap != 0
-   writes float[4] per pixel instead).  `stream` is a hipStream_t (NULL = the
-   invocation's own stream).  Asynchronous. */
+   writes float[4] per pixel instead -- its rows are the *frame's* render width apart,
+   16 * render_width bytes, whatever the region's width and row_stride, like the
+   reference's float-map bands (new_template.c.in:297); the region's columns sit at the
+   start of each row).  `stream` is a hipStream_t (NULL = the invocation's own stream).
+   Asynchronous. */
 int mmhip_render(mmhip_invocation *inv, int frame, float t, int region_x, int region_y, int region_w, int region_h,
                  int first_row, int last_row, void *out_device, int row_stride, int bpp, int floatmap, void *stream);
 /* The CLI's -o: supersampled render of a region (two slices + 1-1-2-1-1 / 6 byte combine,

@@ -279,7 +279,8 @@ class Invocation:
     def render_rows(self, out_ptr, first_row, last_row, t=0.0, frame=0, row_stride=None, bpp=4, floatmap=False,
                     stream=0, region=None):
         """Asynchronously renders rows [first_row,last_row) into device memory at out_ptr
-        (the reference's calc_lines band, mathmap_common.c:837-846)."""
+        (the reference's calc_lines band, mathmap_common.c:837-846).  With `floatmap` the rows of the output are
+        the frame's render width apart (16 * render_width bytes, new_template.c.in:297), whatever the region and row_stride."""
         rx, ry, rw, rh = region if region is not None else (0, 0, self.render_width, self.render_height)
         if row_stride is None:
             row_stride = rw * bpp
