@@ -27,7 +27,10 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-BUILD = os.path.join(HERE, "_build")
+# MM_ORACLE_SANITIZE=1: the oracle's own C (runtime + generated filters) under AddressSanitizer + UBSan, in a build
+# directory of its own; run python with LD_PRELOAD=$(gcc -print-file-name=libasan.so) (tools/asan_oracle.sh)
+SANITIZE = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if os.environ.get("MM_ORACLE_SANITIZE") else []
+BUILD = os.path.join(HERE, "_build_san" if SANITIZE else "_build")
 
 CTYPES = {"int": "int", "float": "float", "complex": "float _Complex", "color": "color_t",
           "curve": "int", "gradient": "int", "image": "mmo_image"}
@@ -439,7 +442,7 @@ def build_runtime():
         src = os.path.join(HERE, name + ".c")
         if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
             tmp = "%s.%d.tmp" % (obj, os.getpid())
-            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-o", tmp, src])
+            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment"] + SANITIZE + ["-o", tmp, src])
             os.replace(tmp, obj)
         objs.append(obj)
     return objs
@@ -452,7 +455,7 @@ def runtime_library():
     so = os.path.join(BUILD, "libmm_oracle_rt.so")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in rt):
         tmp = "%s.%d.tmp" % (so, os.getpid())
-        _run(["gcc", "-shared", "-o", tmp] + rt + ["-lm"])
+        _run(["gcc", "-shared"] + SANITIZE + ["-o", tmp] + rt + ["-lm"])
         os.replace(tmp, so)
     return C.CDLL(so)
 
@@ -508,10 +511,10 @@ class CpuFilter:
             with open(cfile, "w") as f:
                 f.write(self.source)
             # the reference's CGEN_CC / CGEN_LD (Makefile:58-60)
-            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE] + LIBM_NO_BUILTIN + list(extra_cflags) +
+            _run(["gcc", "-O2", "-c", "-fPIC", "-Wno-comment", "-I", HERE] + SANITIZE + LIBM_NO_BUILTIN + list(extra_cflags) +
                  ["-o", ofile, cfile])
             tmp_so = "%s.%d.tmp" % (so, os.getpid())
-            _run(["gcc", "-shared", "-o", tmp_so, ofile] + rt + noise + ["-lm"])
+            _run(["gcc", "-shared"] + SANITIZE + ["-o", tmp_so, ofile] + rt + noise + ["-lm"])
             os.replace(tmp_so, so)
             for f in (cfile, ofile):
                 try:
