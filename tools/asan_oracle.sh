@@ -34,3 +34,4 @@ for rich in (False, True):
         ran += 1
 print("oracle renders under ASan + UBSan:", ran, "filters x 3 settings, clean")
 PY
+rm -rf oracle/_build_san      # (224 MB of instrumented objects: not something to ship to the GPU box)
