@@ -255,3 +255,33 @@ def test_render_of_a_native_result_on_a_non_square_frame(size):
     plain = "filter f (image in, float s: 0-1 (0.02)) b = gaussian_blur(in, s * 3, s * 1.5); c = gaussian_blur(b, s, s); b(xy) * 0.7 + c(xy * 0.9) * 0.3 end"
     _, pi = make_invocation(plain, w, h, {}, {"in": img})
     assert np.array_equal(got, pi.render(t=0.25)) == (w == h)      # a copy on the square frame only
+
+
+@pytest.mark.parametrize("seed,rich", [(5, False), (6, False), (21, False), (27, False), (45, False),
+                                       (11, True), (17, True), (19, True), (65, True), (157, True)])
+def test_generated_filters_of_the_native_flow_fuzzer(seed, rich):
+    """A slice of tools/fuzz_native_flow.py in the suite: the seeds its first runs failed on (call sites in loops and
+    under pixel-dependent control, loops of both slices, render() behind a resize wrapper, closures on results of natives
+    on closures, unassigned image handles), at three (mode, n, t) settings each."""
+    import importlib.util
+    import os
+    from tests.conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_native_flow", os.path.join(ROOT, "tools", "fuzz_native_flow.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    w, h = [(96, 64), (64, 96), (80, 80), (112, 48)][seed % 4] if rich else (96, 64)
+    iw, ih = [(w, h), (50, 70), (w, h), (131, 40)][(seed // 4) % 4] if rich else (w, h)
+    img = np.ascontiguousarray(F.synthetic_image(iw, ih, seed=3))
+    g = fz.Gen(seed, rich)
+    src = g.filter()
+    assert g.calls_in_loops <= 16
+    flt, inv = make_invocation(src, w, h, {}, {"in": img})
+    cf = CpuFilter(flt.ir_json_raw)
+    fft = "convolve(" in src or "visualize_fft(" in src
+    for mode, n, t in ((1, 2, 0.25), (2, 3, 0.75), (0, 1, 0.6)):
+        inv.set("mode", mode)
+        inv.set("n", n)
+        got = inv.render(t=t)
+        want = cf.render(w, h, uservals={"mode": mode, "n": n}, images={"in": img}, t=t)
+        mx, nd, _ = stats(got, want)
+        assert (mx == 0) or (fft and mx <= 1 and nd <= 0.001 * got.size), (seed, rich, mode, n, t, mx, nd)
